@@ -1,0 +1,114 @@
+"""ctypes front end of liboracle.so (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = (not os.path.exists(so)) or any(
+        os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-B", "-C", _HERE, "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        L.oracle_init_prand.argtypes = [C.c_uint]
+        L.oracle_prand.restype = C.c_int
+        L.oracle_fill_random_fullpos.argtypes = [C.c_int, C.c_int, dp, C.c_int]
+        L.oracle_fill_random_full.argtypes = [C.c_int, C.c_int, dp, C.c_int]
+        L.oracle_fill_random_hessenberg.argtypes = [C.c_int, dp, C.c_int]
+        L.oracle_hessenberg.argtypes = [C.c_int] * 4 + [dp, C.c_int, dp, C.c_int]
+        L.oracle_hessenberg.restype = C.c_int
+        L.oracle_default_panel_width.argtypes = [C.c_int]
+        L.oracle_default_panel_width.restype = C.c_int
+        L.oracle_residual_u.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int]
+        L.oracle_residual_u.restype = C.c_double
+        L.oracle_orthogonality_u.argtypes = [C.c_int, dp, C.c_int]
+        L.oracle_orthogonality_u.restype = C.c_double
+        L.oracle_count_below_subdiagonal.argtypes = [C.c_int, dp, C.c_int]
+        L.oracle_count_below_subdiagonal.restype = C.c_long
+        L.oracle_dlarfg.argtypes = [C.c_int, dp, dp]
+        L.oracle_dlarfg.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags.f_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def ld_for(n):
+    """test/common/common.c:99 -- leading dimension rounded up to 8 doubles."""
+    return (n + 7) // 8 * 8
+
+
+def random_fullpos(n, seed=2019, ld=None):
+    """The test driver's default Hessenberg input (test/hessenberg/experiment.c:102)."""
+    ld = ld or ld_for(n)
+    A = np.zeros((ld, n), order="F")
+    lib().oracle_init_prand(seed)
+    lib().oracle_fill_random_fullpos(n, n, _p(A), ld)
+    return A
+
+
+def random_hessenberg(n, seed=2019, ld=None):
+    ld = ld or ld_for(n)
+    A = np.zeros((ld, n), order="F")
+    lib().oracle_init_prand(seed)
+    lib().oracle_fill_random_hessenberg(n, _p(A), ld)
+    return A
+
+
+def identity(n, ld=None):
+    ld = ld or ld_for(n)
+    Q = np.zeros((ld, n), order="F")
+    Q[np.arange(n), np.arange(n)] = 1.0
+    return Q
+
+
+def default_panel_width(n):
+    return lib().oracle_default_panel_width(n)
+
+
+def hessenberg(A, Q, begin=0, end=None, panel_width=None):
+    """In-place oracle reduction; A, Q are (ld, n) Fortran arrays."""
+    n = A.shape[1]
+    end = n if end is None else end
+    pw = panel_width or default_panel_width(n)
+    rc = lib().oracle_hessenberg(n, begin, end, pw, _p(A), A.shape[0], _p(Q), Q.shape[0])
+    if rc != 0:
+        raise MemoryError("oracle_hessenberg")
+    return A, Q
+
+
+def residual_u(Q, H, A):
+    n = A.shape[1]
+    return lib().oracle_residual_u(n, _p(Q), Q.shape[0], _p(H), H.shape[0], _p(A), A.shape[0])
+
+
+def orthogonality_u(Q):
+    n = Q.shape[1]
+    return lib().oracle_orthogonality_u(n, _p(Q), Q.shape[0])
+
+
+def count_below_subdiagonal(H):
+    n = H.shape[1]
+    return lib().oracle_count_below_subdiagonal(n, _p(H), H.shape[0])
