@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X Hessenberg(+Schur) hot path -- driver contract.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full reduction of one synthetic n x n matrix (the reference test
+driver's LCG input, seed 2019, generated directly in HBM; Q = I), inputs resident in
+HBM when the timed region starts.  Prints ONE JSON line (rank 0).
+
+At N > 1 every rank reduces its own matrix on its own GPU (replicas, weak scaling):
+the block-column sharding of SURVEY.md section 8(e) is not built yet.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def hess_flops(n):
+    return 16.0 / 3.0 * n ** 3      # 10/3 n^3 (A) + 2 n^3 (Q)
+
+
+def cpu_baseline(n_sample):
+    """The CPU oracle (kind "port": the restatement of the reference algorithm) timed on
+    this host's cores on a bounded sample of the same workload (smaller n, same input
+    generator, same default panel width rule)."""
+    import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    A = O.random_fullpos(n_sample)
+    Q = O.identity(n_sample)
+    t0 = time.perf_counter()
+    O.hessenberg(A, Q)
+    dt = time.perf_counter() - t0
+    return {
+        "value": hess_flops(n_sample) / dt / 1e9, "unit": "GFLOP/s", "cores": cores,
+        "kind": "port",
+        "sample": f"oracle Hessenberg (16/3 n^3 flop) of the LCG matrix at n={n_sample}, "
+                  f"{dt:.1f} s, OpenMP over {cores} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--cpu-n", type=int, default=2500, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--sample-every", type=int, default=16,
+                    help="time every k-th panel-gemv launch with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+
+    import starneig_amd as S
+    S.node_init(1, 1, S.NO_MESSAGES)
+
+    n = args.n
+    tA0 = S.device_matrix(n)
+    assert S.lcg_fill_device(tA0, n, n, seed=2019 + rank, mode=0) == 0
+    tA = torch.empty_like(tA0)
+    tQ = S.device_matrix(n)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(sample_every):
+        tA.copy_(tA0)
+        S.set_matrix_device(tQ, n, n, 0.0, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=sample_every)
+        torch.cuda.synchronize()
+        assert rc == 0
+        return time.perf_counter() - t0, st
+
+    for _ in range(args.warmup):
+        one_step(0)
+
+    barrier()
+    step_s, stats = [], []
+    for _ in range(args.steps):
+        dt, st = one_step(args.sample_every)
+        step_s.append(dt)
+        stats.append(st)
+    barrier()
+    total = sum(step_s)         # input reset (copy + identity) is outside the timed region
+    t = torch.tensor([total], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    total = t.item()
+
+    # correctness of the last step, on the GPU (reference acceptance checks)
+    rc, chk = S.check_device(tQ, tA, tA0, n=n)
+    assert rc == 0
+
+    if rank == 0:
+        ms_per_step = total / args.steps * 1e3
+        value = world * args.steps * hess_flops(n) / total / 1e9
+        sm = sum(s["gemv_sampled_ms"] for s in stats)
+        sb = sum(s["gemv_sampled_bytes"] for s in stats)
+        nl = sum(s["gemv_sampled_launches"] for s in stats)
+        achieved = sb / (sm * 1e-3) / 1e9 if sm > 0 else None
+        out = {
+            "metric": "GFLOP/s Hessenberg+Schur, n=20000 real dense, 1/2/4/8 MI355X; residual",
+            "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"Hessenberg reduction with Q accumulated, n={n}, LCG input seed 2019 "
+                            f"(BASELINE config 3 without its Schur leg, which is not built yet: "
+                            f"value = 16/3 n^3 flop / Hessenberg time)",
+                "n": n, "panel_width": S.default_panel_width(n),
+                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+                "residual_u": chk["residual_u"], "orthogonality_u": chk["orthogonality_u"],
+                "below_subdiagonal_nonzeros": chk["below_subdiagonal"],
+                "executed_gemm_tflop_per_step": stats[-1]["gemm_flops"] / 1e12,
+            },
+            "roofline": {
+                "kernel": "hess_gemv_kernel (panel y = A v, rows H2 of SURVEY 8a)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "launches_timed": nl,
+                "avg_launch_us": (sm / nl * 1e3) if nl else None,
+                "avg_launch_bytes": (sb / nl) if nl else None,
+            },
+        }
+        if world == 1 and args.cpu_n > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n)
+        print(json.dumps(out), flush=True)
+
+    S.node_finalize()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

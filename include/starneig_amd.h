@@ -1,0 +1,65 @@
+/* Device-pointer entry points of the MI355X path (extension of the StarNEig
+ * interface).  The starneig_SEP_SM_* functions of include/starneig/sep_sm.h take
+ * HOST arrays like the reference does (hessenberg/interface.c:138-167 registers
+ * the caller's arrays in place); these take arrays that are already resident in
+ * HBM -- what a caller that keeps its data on the GPU (or a benchmark that must
+ * not time PCIe) binds instead.  Plain pointers and sizes only; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).
+ * All matrices are column-major doubles. */
+#ifndef STARNEIG_AMD_H
+#define STARNEIG_AMD_H
+#include <starneig/error.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces starneig_hessenberg_insert_tasks (hessenberg/core.c:351) + codelets
+ * (hessenberg/cpu.c:50-560, cuda.cu:62-309) on device-resident data.
+ * panel_width <= 0 selects the reference default (hessenberg/interface.c:74-78).
+ * dQ may be NULL (Q not accumulated).  stats (may be NULL) is double[8]:
+ * in  [7] = k > 0: time every k-th panel-gemv launch with HIP events (0 = off);
+ * out [0] total ms (events on `stream`), [1] algorithmic bytes of all panel-gemv
+ * launches, [2] executed GEMM flops, [3] summed duration (ms) and [4] algorithmic
+ * bytes of the sampled gemv launches, [5] gemv launches, [6] sampled launches.
+ * Blocks until the result is complete. */
+starneig_error_t starneig_amd_hessenberg_device(
+    int n, int begin, int end, int panel_width,
+    double *dA, int ldA, double *dQ, int ldQ, void *stream, double *stats);
+
+/* fp64 MFMA GEMM, BLAS dgemm semantics on device pointers (the kernel behind
+ * rows H4-H8 and S3; replaces cblas_dgemm/cublasDgemm call sites). */
+starneig_error_t starneig_amd_dgemm_device(
+    char transA, char transB, int m, int n, int k, double alpha,
+    double const *dA, int ldA, double const *dB, int ldB, double beta,
+    double *dC, int ldC, void *stream);
+
+/* The reference test driver's LCG inputs generated directly in HBM
+ * (test/common/common.c:56-59, test/common/init.c:93-120):
+ * mode 0 = prand/PRAND_MAX in [0,1] ("fullpos"), mode 1 = 2*prand/PRAND_MAX-1. */
+starneig_error_t starneig_amd_lcg_fill_device(
+    int m, int n, unsigned seed, int mode, double *dA, int ldA, void *stream);
+
+/* A <- value everywhere, diag on the diagonal. */
+starneig_error_t starneig_amd_set_matrix_device(
+    int m, int n, double value, double diag, double *dA, int ldA, void *stream);
+
+/* The reference's acceptance checks evaluated on the GPU
+ * (test/common/checks.c:180-208): out[0] = 2^52 ||Q H Q^T - A||_F / ||A||_F,
+ * out[1] = 2^52 ||Q Q^T - I||_F / sqrt(n), out[2] = number of non-zero entries
+ * below the first sub-diagonal of H (test/common/hooks.c:434-456).
+ * dWork1/dWork2: n x n scratch (ld n). */
+starneig_error_t starneig_amd_check_device(
+    int n, double const *dQ, int ldQ, double const *dH, int ldH,
+    double const *dA0, int ldA0, double *dWork1, double *dWork2,
+    double out[3], void *stream);
+
+/* hessenberg/interface.c:74-78 */
+int starneig_amd_default_panel_width(int n);
+
+/* Frees cached device workspaces (they are otherwise kept between calls). */
+void starneig_amd_release_workspace(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

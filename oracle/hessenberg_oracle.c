@@ -371,7 +371,8 @@ int oracle_hessenberg(int n, int begin, int end, int panel_width,
 /* hessenberg/interface.c:74-78 */
 int oracle_default_panel_width(int n)
 {
-    int w = (int)ceil((0.001875596476*n + 273.5908216)/8.0)*8;
+    int a = (int)(0.001875596476*n + 273.5908216);   /* divceil(int,int): common.h:207 */
+    int w = (a+7)/8*8;
     return MAX(64, w);
 }
 

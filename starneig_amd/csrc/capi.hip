@@ -1,0 +1,271 @@
+// C-ABI of the MI355X path: the StarNEig shared-memory interface for the
+// Hessenberg/Schur hot path (include/starneig/*.h) plus the device-pointer
+// extension (include/starneig_amd.h).  There is deliberately no CPU fallback:
+// without a usable gfx950 device starneig_node_init() aborts.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <starneig/starneig.h>
+#include <starneig_amd.h>
+
+namespace sn {
+void hessenberg_release_workspace();
+void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
+    double ident, double *acc);
+void count_below(hipStream_t s, int n, double const *H, int ldh, double *acc);
+}
+
+namespace {
+
+struct NodeState {                      // reference: static state, common/node.c:61-92
+    bool initialized = false;
+    int cores = 0, gpus = 0;
+    bool messages = true, verbose = true, pinning = false;
+    int device = 0;
+} g_node;
+
+void require_device()
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        fprintf(stderr, "[starneig-amd] fatal: no HIP device available (%s). "
+            "This library has no CPU path.\n", hipGetErrorString(e));
+        abort();
+    }
+    hipDeviceProp_t prop;
+    SN_HIP_CHECK(hipGetDevice(&g_node.device));
+    SN_HIP_CHECK(hipGetDeviceProperties(&prop, g_node.device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && g_node.messages)
+        fprintf(stderr, "[starneig-amd] warning: device is %s, kernels are built for gfx950\n",
+            prop.gcnArchName);
+}
+
+int default_panel_width(int n)          // hessenberg/interface.c:74-78
+{
+    int a = (int)(0.001875596476 * n + 273.5908216);   // divceil(int,int), common/common.h:207
+    int w = (a + 7) / 8 * 8;
+    return std::max(64, w);
+}
+
+} // namespace
+
+extern "C" {
+
+#define SN_API __attribute__((visibility("default")))
+
+SN_API void starneig_node_init(int cores, int gpus, starneig_flag_t flags)
+{
+    if (g_node.initialized) {           // common/node.c:442-443: fatal
+        fprintf(stderr, "[starneig-amd] fatal: the node is already initialized.\n");
+        abort();
+    }
+    g_node.verbose = !(flags & STARNEIG_NO_VERBOSE);
+    g_node.messages = (flags & STARNEIG_NO_MESSAGES) != STARNEIG_NO_MESSAGES;
+    require_device();
+    g_node.cores = cores == STARNEIG_USE_ALL ? 1 : std::max(1, cores);
+    // one process drives one GPU; `gpus` other than 1 is accepted for interface
+    // compatibility (multi-GPU runs are one process per GPU over RCCL)
+    g_node.gpus = 1;
+    (void)gpus;
+    g_node.initialized = true;
+}
+
+SN_API int starneig_node_initialized(void) { return g_node.initialized ? 1 : 0; }
+SN_API int starneig_node_get_cores(void) { return g_node.cores; }
+SN_API void starneig_node_set_cores(int cores) { g_node.cores = std::max(1, cores); }
+SN_API int starneig_node_get_gpus(void) { return g_node.gpus; }
+SN_API void starneig_node_set_gpus(int gpus) { (void)gpus; g_node.gpus = 1; }
+SN_API void starneig_node_enable_pinning(void) { g_node.pinning = true; }
+SN_API void starneig_node_disable_pinning(void) { g_node.pinning = false; }
+
+SN_API void starneig_node_finalize(void)
+{
+    if (!g_node.initialized) return;
+    SN_HIP_CHECK(hipDeviceSynchronize());
+    sn::hessenberg_release_workspace();
+    g_node.initialized = false;
+}
+
+SN_API void starneig_hessenberg_init_conf(struct starneig_hessenberg_conf *conf)
+{
+    conf->tile_size = STARNEIG_HESSENBERG_DEFAULT_TILE_SIZE;
+    conf->panel_width = STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH;
+}
+
+SN_API void starneig_schur_init_conf(struct starneig_schur_conf *conf)
+{
+    // every field -1 = "choose the default" (schur/interface.c:167-188)
+    static const struct starneig_schur_conf all_default = {
+        -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1.0, -1.0, -1.0 };
+    *conf = all_default;
+}
+
+SN_API int starneig_amd_default_panel_width(int n) { return default_panel_width(n); }
+
+SN_API void starneig_amd_release_workspace(void) { sn::hessenberg_release_workspace(); }
+
+// ---- host-array interface (in place, like the reference) ----------------------
+
+SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
+    struct starneig_hessenberg_conf *conf, int n, int begin, int end,
+    double A[], int ldA, double Q[], int ldQ)
+{
+    if (n < 1)      return -2;           // hessenberg/interface.c:144-150
+    if (begin < 0)  return -3;
+    if (n < end)    return -4;
+    if (A == NULL)  return -5;
+    if (ldA < n)    return -6;
+    if (Q == NULL)  return -7;
+    if (ldQ < n)    return -8;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+
+    int panel_width = STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH;
+    if (conf != NULL) {
+        if (conf->tile_size != STARNEIG_HESSENBERG_DEFAULT_TILE_SIZE && conf->tile_size < 8)
+            return STARNEIG_INVALID_CONFIGURATION;          // interface.c:68-71
+        panel_width = conf->panel_width;
+        if (panel_width != STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH && panel_width < 8)
+            return STARNEIG_INVALID_CONFIGURATION;          // interface.c:80-83
+    }
+    if (panel_width == STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH)
+        panel_width = default_panel_width(n);
+
+    int const ld = (int)sn::roundup(n, 16);
+    size_t const bytes = (size_t)ld * n * sizeof(double);
+    double *dA = nullptr, *dQ = nullptr;
+    SN_HIP_CHECK(hipMalloc((void **)&dA, bytes));
+    SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+    if (g_node.pinning) {
+        hipHostRegister(A, (size_t)ldA * n * sizeof(double), hipHostRegisterDefault);
+        hipHostRegister(Q, (size_t)ldQ * n * sizeof(double), hipHostRegisterDefault);
+    }
+    SN_HIP_CHECK(hipMemset(dA, 0, bytes));
+    SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
+    SN_HIP_CHECK(hipMemcpy2D(dA, (size_t)ld * 8, A, (size_t)ldA * 8, (size_t)n * 8, n,
+        hipMemcpyHostToDevice));
+    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n,
+        hipMemcpyHostToDevice));
+
+    int rc = sn::hessenberg_device(nullptr, n, begin, end, panel_width, dA, ld, dQ, ld, nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+
+    SN_HIP_CHECK(hipMemcpy2D(A, (size_t)ldA * 8, dA, (size_t)ld * 8, (size_t)n * 8, n,
+        hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n,
+        hipMemcpyDeviceToHost));
+    if (g_node.pinning) { hipHostUnregister(A); hipHostUnregister(Q); }
+    SN_HIP_CHECK(hipFree(dA));
+    SN_HIP_CHECK(hipFree(dQ));
+    return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
+}
+
+SN_API starneig_error_t starneig_SEP_SM_Hessenberg(
+    int n, double A[], int ldA, double Q[], int ldQ)
+{
+    if (n < 1)      return -1;           // hessenberg/interface.c:175-179
+    if (A == NULL)  return -2;
+    if (ldA < n)    return -3;
+    if (Q == NULL)  return -4;
+    if (ldQ < n)    return -5;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    return starneig_SEP_SM_Hessenberg_expert(NULL, n, 0, n, A, ldA, Q, ldQ);
+}
+
+// ---- device-pointer extension -------------------------------------------------
+
+SN_API starneig_error_t starneig_amd_hessenberg_device(
+    int n, int begin, int end, int panel_width,
+    double *dA, int ldA, double *dQ, int ldQ, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (begin < 0)             return -2;
+    if (n < end)               return -3;
+    if (dA == NULL)            return -5;
+    if (ldA < n)               return -6;
+    if (dQ != NULL && ldQ < n) return -8;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    if (panel_width <= 0) panel_width = default_panel_width(n);
+    if (panel_width < 8) return STARNEIG_INVALID_CONFIGURATION;
+    sn::HessenbergTimings tm;
+    if (stats) tm.sample_every = (int)stats[7];
+    hipStream_t s = (hipStream_t)stream;
+    int rc = sn::hessenberg_device(s, n, begin, end, panel_width, dA, ldA, dQ, ldQ,
+        stats ? &tm : nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    if (stats) {
+        stats[0] = tm.total_ms; stats[1] = tm.gemv_bytes; stats[2] = tm.gemm_flops;
+        stats[3] = tm.sampled_ms; stats[4] = tm.sampled_bytes;
+        stats[5] = (double)tm.gemv_launches; stats[6] = (double)tm.sampled_launches;
+    }
+    return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
+}
+
+SN_API starneig_error_t starneig_amd_dgemm_device(
+    char transA, char transB, int m, int n, int k, double alpha,
+    double const *dA, int ldA, double const *dB, int ldB, double beta,
+    double *dC, int ldC, void *stream)
+{
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0) return -5;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::dgemm((hipStream_t)stream, transA, transB, m, n, k, alpha, dA, ldA, dB, ldB, beta, dC, ldC);
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_amd_lcg_fill_device(
+    int m, int n, unsigned seed, int mode, double *dA, int ldA, void *stream)
+{
+    if (m < 0) return -1;
+    if (n < 0) return -2;
+    if (dA == NULL) return -5;
+    if (ldA < m) return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::lcg_fill((hipStream_t)stream, m, n, seed, mode, dA, ldA);
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_amd_set_matrix_device(
+    int m, int n, double value, double diag, double *dA, int ldA, void *stream)
+{
+    if (dA == NULL) return -5;
+    if (ldA < m) return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::set_matrix((hipStream_t)stream, m, n, value, diag, dA, ldA);
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_amd_check_device(
+    int n, double const *dQ, int ldQ, double const *dH, int ldH,
+    double const *dA0, int ldA0, double *dWork1, double *dWork2,
+    double out[3], void *stream)
+{
+    if (n < 1) return -1;
+    if (!dQ || !dH || !dA0 || !dWork1 || !dWork2 || !out) return STARNEIG_INVALID_ARGUMENTS;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    hipStream_t s = (hipStream_t)stream;
+    double *acc = nullptr;
+    SN_HIP_CHECK(hipMalloc((void **)&acc, 4 * sizeof(double)));
+    SN_HIP_CHECK(hipMemsetAsync(acc, 0, 4 * sizeof(double), s));
+    // W1 = Q H ; W2 = W1 Q^T ; ||W2 - A||_F / ||A||_F       (checks.c:180-194)
+    sn::dgemm(s, 'N', 'N', n, n, n, 1.0, dQ, ldQ, dH, ldH, 0.0, dWork1, n);
+    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dWork1, n, dQ, ldQ, 0.0, dWork2, n);
+    sn::sumsq_diff(s, n, n, dWork2, n, dA0, ldA0, 0.0, acc + 0);
+    sn::sumsq_diff(s, n, n, dA0, ldA0, nullptr, 0, 0.0, acc + 1);
+    // ||Q Q^T - I||_F / sqrt(n)                              (checks.c:196-208)
+    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dQ, ldQ, dQ, ldQ, 0.0, dWork1, n);
+    sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 2);
+    sn::count_below(s, n, dH, ldH, acc + 3);
+    double h[4];
+    SN_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, s));
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    SN_HIP_CHECK(hipFree(acc));
+    out[0] = std::ldexp(std::sqrt(h[0]) / std::sqrt(h[1]), 52);
+    out[1] = std::ldexp(std::sqrt(h[2]) / std::sqrt((double)n), 52);
+    out[2] = h[3];
+    return STARNEIG_SUCCESS;
+}
+
+} // extern "C"

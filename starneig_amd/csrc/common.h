@@ -1,0 +1,60 @@
+// Shared declarations of the MI355X (gfx950) Hessenberg/Schur path.
+// Everything here is device-side plumbing behind the C-ABI of include/starneig/*.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define SN_HIP_CHECK(expr)                                                      \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            fprintf(stderr, "[starneig-amd] HIP error %s at %s:%d: %s\n",       \
+                hipGetErrorName(e_), __FILE__, __LINE__, hipGetErrorString(e_));\
+            abort();                                                            \
+        }                                                                       \
+    } while (0)
+
+namespace sn {
+
+static inline int divceil(int a, int b) { return (a + b - 1) / b; }
+static inline size_t roundup(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- fp64 MFMA GEMM (dgemm_mfma.hip) ---------------------------------------
+// C(m x n) = alpha * op(A) * op(B) + beta * C, column-major, BLAS semantics.
+// transA/transB: 'N' or 'T'.  beta == 0 never reads C.
+void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
+    double alpha, double const *A, int lda, double const *B, int ldb,
+    double beta, double *C, int ldc);
+
+// ---- small helpers (util.hip) -----------------------------------------------
+void copy_matrix(hipStream_t s, int m, int n, double const *A, int lda,
+    double *B, int ldb);
+void set_matrix(hipStream_t s, int m, int n, double value, double diag,
+    double *A, int lda);
+// Fill with the reference test driver's LCG (test/common/common.c:56-59),
+// element e (column-major order, ld skipped) = state after e+1 steps.
+// mode 0: prand/PRAND_MAX, mode 1: 2*prand/PRAND_MAX-1.
+void lcg_fill(hipStream_t s, int m, int n, unsigned seed, int mode,
+    double *A, int lda);
+
+// ---- Hessenberg (hessenberg.hip) --------------------------------------------
+struct HessenbergTimings {
+    int sample_every = 0;       // in: time every k-th gemv launch with HIP events (0 = off)
+    float total_ms = 0.f;       // whole reduction, event-timed on the caller's stream
+    double gemv_bytes = 0.0;    // algorithmic bytes streamed by all panel gemv launches
+    double gemm_flops = 0.0;    // executed GEMM flops (all updates)
+    long gemv_launches = 0;
+    long sampled_launches = 0;
+    double sampled_bytes = 0.0; // algorithmic bytes of the sampled launches
+    double sampled_ms = 0.0;    // their summed kernel durations
+};
+
+// Reduces columns [begin,end) of the device-resident n x n matrix dA (ld ldA)
+// and accumulates dQ <- dQ*U.  Blocking w.r.t. the given stream is left to the
+// caller: all work is enqueued on ctx streams and joined back into `s`.
+int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
+    double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *timings);
+
+} // namespace sn

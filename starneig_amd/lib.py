@@ -1,0 +1,205 @@
+"""ctypes binding of libstarneig_amd.so -- the C-ABI drop-in boundary.
+
+The functions mirror the reference's C interface one to one (same names without
+the ``starneig_`` prefix, same argument order, same return codes):
+``SEP_SM_Hessenberg`` <-> reference src/include/starneig/sep_sm.h:89-92, etc.
+There is no fallback of any kind: a missing library raises at import of the
+symbol table, a missing GPU aborts in ``node_init``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarneig_amd.so")
+
+# error codes, include/starneig/error.h
+SUCCESS = 0
+GENERIC_ERROR = 1
+NOT_INITIALIZED = 2
+INVALID_CONFIGURATION = 3
+INVALID_ARGUMENTS = 4
+DID_NOT_CONVERGE = 6
+
+USE_ALL = -1
+DEFAULT = 0x0
+HINT_SM = 0x0
+NO_VERBOSE = 0x10
+NO_MESSAGES = 0x30
+
+
+class HessenbergConf(C.Structure):
+    _fields_ = [("tile_size", C.c_int), ("panel_width", C.c_int)]
+
+
+class SchurConf(C.Structure):
+    _fields_ = [(k, C.c_int) for k in (
+        "iteration_limit", "tile_size", "small_limit", "aed_window_size", "aed_nibble",
+        "aed_parallel_soft_limit", "aed_parallel_hard_limit", "shift_origin", "shift_count",
+        "window_size", "shifts_per_window", "update_width", "update_height")] + [
+        ("left_threshold", C.c_double), ("right_threshold", C.c_double),
+        ("inf_threshold", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# every symbol include/*.h declares, with its signature
+SIGNATURES = {
+    "starneig_node_init": (None, [C.c_int, C.c_int, C.c_uint]),
+    "starneig_node_initialized": (C.c_int, []),
+    "starneig_node_get_cores": (C.c_int, []),
+    "starneig_node_set_cores": (None, [C.c_int]),
+    "starneig_node_get_gpus": (C.c_int, []),
+    "starneig_node_set_gpus": (None, [C.c_int]),
+    "starneig_node_finalize": (None, []),
+    "starneig_node_enable_pinning": (None, []),
+    "starneig_node_disable_pinning": (None, []),
+    "starneig_hessenberg_init_conf": (None, [C.POINTER(HessenbergConf)]),
+    "starneig_schur_init_conf": (None, [C.POINTER(SchurConf)]),
+    "starneig_SEP_SM_Hessenberg": (C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "starneig_SEP_SM_Hessenberg_expert": (
+        C.c_int, [C.POINTER(HessenbergConf), C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "starneig_amd_hessenberg_device": (
+        C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
+    "starneig_amd_dgemm_device": (
+        C.c_int, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int,
+                  _vp, C.c_int, C.c_double, _vp, C.c_int, _vp]),
+    "starneig_amd_lcg_fill_device": (
+        C.c_int, [C.c_int, C.c_int, C.c_uint, C.c_int, _vp, C.c_int, _vp]),
+    "starneig_amd_set_matrix_device": (
+        C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_int, _vp]),
+    "starneig_amd_check_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _dp, _vp]),
+    "starneig_amd_default_panel_width": (C.c_int, [C.c_int]),
+    "starneig_amd_release_workspace": (None, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m starneig_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)        # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+# ---- life cycle (reference node.h:178-220) --------------------------------------
+
+def node_init(cores=USE_ALL, gpus=USE_ALL, flags=DEFAULT):
+    load().starneig_node_init(cores, gpus, flags)
+
+
+def node_initialized():
+    return bool(load().starneig_node_initialized())
+
+
+def node_finalize():
+    load().starneig_node_finalize()
+
+
+def hessenberg_init_conf():
+    conf = HessenbergConf()
+    load().starneig_hessenberg_init_conf(C.byref(conf))
+    return conf
+
+
+# ---- host-array interface ---------------------------------------------------------
+
+def _host_ptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.f_contiguous
+    return a.ctypes.data
+
+
+def SEP_SM_Hessenberg(n, A, ldA, Q, ldQ):
+    """reference sep_sm.h:89-92; A, Q are Fortran-ordered (ld, n) float64 arrays or None."""
+    return load().starneig_SEP_SM_Hessenberg(n, _host_ptr(A), ldA, _host_ptr(Q), ldQ)
+
+
+def SEP_SM_Hessenberg_expert(conf, n, begin, end, A, ldA, Q, ldQ):
+    """reference sep_sm.h:380-384."""
+    cp = C.byref(conf) if conf is not None else None
+    return load().starneig_SEP_SM_Hessenberg_expert(
+        cp, n, begin, end, _host_ptr(A), ldA, _host_ptr(Q), ldQ)
+
+
+# ---- device-pointer extension (torch tensors only carry the memory) ---------------
+
+def _dev_ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_matrix(n, ld=None, m=None):
+    """Column-major (ld x n) fp64 matrix in HBM: a torch tensor of shape (n, ld)."""
+    import torch
+    m = n if m is None else m
+    ld = ld or (m + 15) // 16 * 16
+    return torch.zeros((n, ld), dtype=torch.float64, device="cuda")
+
+
+def hessenberg_device(tA, tQ, n=None, begin=0, end=None, panel_width=-1, stats=False,
+                      sample_every=0):
+    n = tA.shape[0] if n is None else n
+    end = n if end is None else end
+    st = (C.c_double * 8)() if stats else None
+    if stats:
+        st[7] = float(sample_every)
+    rc = load().starneig_amd_hessenberg_device(
+        n, begin, end, panel_width, _dev_ptr(tA), tA.shape[1],
+        _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0, _stream_ptr(), st)
+    if stats:
+        return rc, {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
+                    "gemv_sampled_ms": st[3], "gemv_sampled_bytes": st[4],
+                    "gemv_launches": int(st[5]), "gemv_sampled_launches": int(st[6])}
+    return rc
+
+
+def dgemm_device(transA, transB, m, n, k, alpha, tA, ldA, tB, ldB, beta, tC, ldC):
+    return load().starneig_amd_dgemm_device(
+        transA.encode(), transB.encode(), m, n, k, alpha, _dev_ptr(tA), ldA,
+        _dev_ptr(tB), ldB, beta, _dev_ptr(tC), ldC, _stream_ptr())
+
+
+def lcg_fill_device(t, m, n, seed=2019, mode=0):
+    return load().starneig_amd_lcg_fill_device(m, n, seed, mode, _dev_ptr(t), t.shape[1], _stream_ptr())
+
+
+def set_matrix_device(t, m, n, value=0.0, diag=0.0):
+    return load().starneig_amd_set_matrix_device(m, n, value, diag, _dev_ptr(t), t.shape[1], _stream_ptr())
+
+
+def check_device(tQ, tH, tA0, n=None):
+    """Residual / orthogonality in units of u and the count of non-zeros below the
+    sub-diagonal, computed on the GPU (reference test/common/checks.c:180-208)."""
+    import torch
+    n = tA0.shape[0] if n is None else n
+    w1 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    w2 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    out = (C.c_double * 3)()
+    rc = load().starneig_amd_check_device(
+        n, _dev_ptr(tQ), tQ.shape[1], _dev_ptr(tH), tH.shape[1], _dev_ptr(tA0), tA0.shape[1],
+        _dev_ptr(w1), _dev_ptr(w2), out, _stream_ptr())
+    return rc, {"residual_u": out[0], "orthogonality_u": out[1], "below_subdiagonal": int(out[2])}
+
+
+def default_panel_width(n):
+    return load().starneig_amd_default_panel_width(n)

@@ -1,0 +1,75 @@
+"""CPU suite, part 2: the C-ABI library loads, exports every symbol include/*.h
+declares, and reproduces the reference's argument-check table without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import starneig_amd as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for root, _, files in os.walk(inc):
+        for f in files:
+            text = open(os.path.join(root, f)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names.update(re.findall(r"\b(starneig_[A-Za-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_every_declared_symbol_is_exported():
+    lib = S.lib.load()
+    declared = declared_symbols()
+    assert declared, "no declarations found"
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+    # and the python binding knows each of them
+    assert declared == set(S.lib.SIGNATURES)
+
+
+def test_hessenberg_argument_checks():
+    """hessenberg/interface.c:175-179 and :144-150 (checks precede the init check)."""
+    n, ld = 5, 8
+    A = np.zeros((ld, n), order="F"); Q = np.zeros((ld, n), order="F")
+    assert S.SEP_SM_Hessenberg(0, A, ld, Q, ld) == -1
+    assert S.SEP_SM_Hessenberg(n, None, ld, Q, ld) == -2
+    assert S.SEP_SM_Hessenberg(n, A, n - 1, Q, ld) == -3
+    assert S.SEP_SM_Hessenberg(n, A, ld, None, ld) == -4
+    assert S.SEP_SM_Hessenberg(n, A, ld, Q, n - 1) == -5
+    e = S.SEP_SM_Hessenberg_expert
+    assert e(None, 0, 0, n, A, ld, Q, ld) == -2
+    assert e(None, n, -1, n, A, ld, Q, ld) == -3
+    assert e(None, n, 0, n + 1, A, ld, Q, ld) == -4
+    assert e(None, n, 0, n, None, ld, Q, ld) == -5
+    assert e(None, n, 0, n, A, n - 1, Q, ld) == -6
+    assert e(None, n, 0, n, A, ld, None, ld) == -7
+    assert e(None, n, 0, n, A, ld, Q, n - 1) == -8
+
+
+def test_not_initialized():
+    n, ld = 5, 8
+    A = np.zeros((ld, n), order="F"); Q = np.zeros((ld, n), order="F")
+    assert not S.node_initialized()
+    assert S.SEP_SM_Hessenberg(n, A, ld, Q, ld) == S.NOT_INITIALIZED
+    assert S.SEP_SM_Hessenberg_expert(None, n, 0, n, A, ld, Q, ld) == S.NOT_INITIALIZED
+
+
+def test_conf_defaults_and_panel_width():
+    conf = S.hessenberg_init_conf()
+    assert (conf.tile_size, conf.panel_width) == (-1, -1)
+    assert [S.default_panel_width(n) for n in (2000, 8000, 20000)] == [280, 288, 312]
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must never import or link the oracle."""
+    pkg = os.path.join(ROOT, "starneig_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.lower() or f == "lib.py" and False, (root, f)
