@@ -5,17 +5,21 @@
 // arithmetic of hessenberg/cpu.c:50-560, as a static schedule of HIP kernels
 // on one device-resident column-major matrix (no tiles, no task graph).
 //
-// Per panel column j (global pivot row piv = i+1+j) the dependent chain is
-//   colA  : finish Y(:,j-1) from the gemv partials, p' = P(:,j) - Y V(piv-1,:)^T,
-//           partial w = V^T p'                       (cpu.c:98-115, :253-270)
-//   colB  : w <- T^T * sum(partials)                 (cpu.c:118-120)
-//   colC  : p'' = p' - V w, partial ||p''(piv+1:)||^2, partial V^T p''
-//                                                    (cpu.c:123-130, :263-264)
-//   colD  : dlarfg scalars, w_v = V^T v, T(0:j,j) = -tau T w_v (cpu.c:137-160, :277-284)
-//   gemv  : y = A(i+1:end, piv:end) v  -- THE HBM-bound kernel (cpu.c:217-219,
-//           cuda.cu:62-107): every trailing element is streamed once per column.
-// All panel vectors/matrices (P,V,Y) are indexed by GLOBAL row so that the
-// 16-byte row pairs of the gemv stay aligned for every panel offset.
+// Per panel column j (global pivot row piv = i+1+j) the dependent chain is three
+// launches:
+//   colA(j) : finish Y(:,j-1) = tau (y - Y w_v) from the gemv partials (cpu.c:253-270),
+//             p' = P(:,j) - Y V(piv-1,:)^T (cpu.c:98-99), w = (V T)^T p' (cpu.c:109-120)
+//   colC(j) : p'' = p' - V w (cpu.c:123-130), ||p''(piv+1:)||^2, V^T p''  (for w_v)
+//   gemv(j) : y = A(i+1:end, piv:end) v  -- THE HBM-bound kernel (cpu.c:217-219,
+//             cuda.cu:62-107): every trailing element is streamed once per column;
+//             extra blocks of the same launch materialise V(:,j) and the new column
+//             of VT = V*T (VT(:,j) = tau (v - VT w_v), which is V t_j + tau v with
+//             t_j = -tau T w_v of cpu.c:277-284), in the gemv's shadow.
+// T itself is never formed: every consumer needs V*T only.  Cross-workgroup sums
+// (w, w_v, the norm) are fp64 atomics into 8 slots that the consumers add up; the
+// reflector scalars (LAPACK dlarfg, cpu.c:137-141) are recomputed by each consumer.
+// All panel matrices (P,V,VT,Y) are indexed by GLOBAL row so that the 16-byte row
+// pairs of the gemv stay aligned for every panel offset.
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -50,229 +54,278 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-constexpr int RB = 256;          // rows per workgroup in the row-parallel column kernels
+constexpr int RB = 128;          // rows per workgroup in the row-parallel column kernels
 constexpr int GEMV_ROWS = 512;   // rows per workgroup of the big gemv (4 waves x 64 lanes x 2)
 constexpr int MAX_SPLIT = 32;
+constexpr int NSLOT = 8;         // atomic accumulator slots (spreads same-address contention)
+constexpr int MAXJ = 512;        // panel width limit of the column kernels
 
-// In-block transposed gemv: out[l] = sum_{r<RB} V[g0+r, l] * sp[r], l < ncols.
+// accumulator layout (doubles): wsum[2][NSLOT][MAXJ], wvsum[2][NSLOT][MAXJ], nrm[2][NSLOT]
+constexpr int ACC_WSUM = 0;
+constexpr int ACC_WVSUM = 2 * NSLOT * MAXJ;
+constexpr int ACC_NRM = 4 * NSLOT * MAXJ;
+constexpr int ACC_TOTAL = ACC_NRM + 2 * NSLOT;
+
+__device__ __forceinline__ double slot_sum(double const *__restrict__ base, int l)
+{
+    double s = 0.0;
+    #pragma unroll
+    for (int k = 0; k < NSLOT; k++) s += base[k * MAXJ + l];
+    return s;
+}
+
+// LAPACK dlarfg scalars from alpha and the sum of squares below it (cpu.c:137-141)
+__device__ __forceinline__ void reflector_scalars(double ssq, double alpha,
+    double &scale, double &tau, double &beta)
+{
+    if (ssq == 0.0) { scale = 0.0; tau = 0.0; beta = alpha; return; }
+    beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+}
+
+__device__ __forceinline__ double nrm_sum(double const *__restrict__ acc, int par)
+{
+    double s = 0.0;
+    #pragma unroll
+    for (int k = 0; k < NSLOT; k++) s += acc[ACC_NRM + par * NSLOT + k];
+    return s;
+}
+
+// In-block transposed gemv: out[l] += sum_{r<RB} M[g0+r, l] * sp[r], l < ncols.
 // 256 threads = 16 row lanes x 16 column groups; 16 lanes read 128 contiguous
-// bytes of one V column, the 16-lane DPP row reduces them.
-__device__ __forceinline__ void block_gemv_t(double const *__restrict__ V, int ldv,
+// bytes of one column, the 16-lane DPP row reduces them, one atomic per column.
+__device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M, int ldm,
     int g0, int ncols, double const *sp, double *__restrict__ out)
 {
     int const rsub = threadIdx.x & 15, csub = threadIdx.x >> 4;
+    double pr[RB / 16];
+    #pragma unroll
+    for (int it = 0; it < RB / 16; it++) pr[it] = sp[it * 16 + rsub];
     for (int l = csub; l < ncols; l += 16) {
-        double const *col = V + (size_t)l * ldv + g0 + rsub;
+        double const *col = M + (size_t)l * ldm + g0 + rsub;
         double acc = 0.0;
-        #pragma unroll 8
-        for (int it = 0; it < RB / 16; it++)
-            acc += col[it * 16] * sp[it * 16 + rsub];
+        #pragma unroll
+        for (int it = 0; it < RB / 16; it++) acc += col[it * 16] * pr[it];
         acc = row16_sum(acc);
-        if (rsub == 0) out[l] = acc;
+        if (rsub == 0) atomicAdd(out + l, acc);
     }
 }
 
-// colA(j), j >= 1.  Row block g0..g0+RB (global rows, clipped to [R0,E)).
+// colA(j), j >= 1.
 __global__ __launch_bounds__(256)
 void hess_colA_kernel(int R0, int E, int j, int ldp,
-    double *__restrict__ P, double const *__restrict__ V, double *__restrict__ Y,
-    double const *__restrict__ ypart, int nsplit,
-    double const *__restrict__ wv,      // j-1 entries (for column j-1)
-    double const *__restrict__ scal,    // scal of column j-1: [scale, tau, beta]
-    double *__restrict__ wpart, int ldw)
+    double *__restrict__ P, double const *__restrict__ V, double const *__restrict__ VT,
+    double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
+    double *__restrict__ acc, double const *__restrict__ scal)
 {
-    __shared__ double s_wv[512], s_vrow[512], s_p[RB];
+    __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_p[RB], s_y[RB], s_pp[RB], s_scal[3];
     int const tid = threadIdx.x;
+    int const r = tid & (RB - 1), h = tid >> 7;
     int const g0 = R0 + blockIdx.x * RB;
-    int const g = g0 + tid;
-    int const pivprev = R0 + j - 1;
-    for (int l = tid; l < j; l += 256) {
-        s_wv[l] = (l < j - 1) ? wv[l] : 0.0;
-        s_vrow[l] = V[(size_t)l * ldp + pivprev];
+    int const g = g0 + r;
+    int const pivprev = R0 + j - 1, parp = (j - 1) & 1, par = j & 1;
+    // scalars of column j-1 as published by gemv(j-1): P(piv-1, j-1) itself is overwritten
+    // with beta by one block of THIS launch, so it must not be re-read here
+    if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
+    __syncthreads();
+    {
+        double const scale = s_scal[0];
+        for (int l = tid; l < j; l += 256) {
+            double vr = V[(size_t)l * ldp + pivprev];          // V(piv-1, l); = 1 for l = j-1
+            s_vrow[l] = vr;
+            s_wv[l] = (l < j - 1)
+                ? vr + scale * slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l) : 0.0;
+        }
     }
     __syncthreads();
-    double pval = 0.0;
+    double yacc = 0.0, pacc = 0.0;
     if (g < E) {
-        double const tau = scal[1], beta = scal[2];
-        double ysum = 0.0;
-        for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
-        double yacc = 0.0, pacc = 0.0;
         double const *yrow = Y + g;
-        int l = 0;
-        for (; l + 4 <= j - 1; l += 4) {
-            double y0 = yrow[(size_t)(l + 0) * ldp], y1 = yrow[(size_t)(l + 1) * ldp];
-            double y2 = yrow[(size_t)(l + 2) * ldp], y3 = yrow[(size_t)(l + 3) * ldp];
-            yacc += y0 * s_wv[l] + y1 * s_wv[l + 1] + y2 * s_wv[l + 2] + y3 * s_wv[l + 3];
-            pacc += y0 * s_vrow[l] + y1 * s_vrow[l + 1] + y2 * s_vrow[l + 2] + y3 * s_vrow[l + 3];
+        int l = h;
+        for (; l + 6 < j - 1; l += 8) {
+            double y0 = yrow[(size_t)(l + 0) * ldp], y1 = yrow[(size_t)(l + 2) * ldp];
+            double y2 = yrow[(size_t)(l + 4) * ldp], y3 = yrow[(size_t)(l + 6) * ldp];
+            yacc += y0 * s_wv[l] + y1 * s_wv[l + 2] + y2 * s_wv[l + 4] + y3 * s_wv[l + 6];
+            pacc += y0 * s_vrow[l] + y1 * s_vrow[l + 2] + y2 * s_vrow[l + 4] + y3 * s_vrow[l + 6];
         }
-        for (; l < j - 1; l++) {
+        for (; l < j - 1; l += 2) {
             double y0 = yrow[(size_t)l * ldp];
             yacc += y0 * s_wv[l];
             pacc += y0 * s_vrow[l];
         }
-        double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
-        Y[(size_t)(j - 1) * ldp + g] = ynew;
-        pacc += ynew * s_vrow[j - 1];
-        pval = P[(size_t)j * ldp + g] - pacc;              // cpu.c:98-99
-        P[(size_t)j * ldp + g] = pval;
-        // column j-1 of P becomes final: beta on the sub-diagonal, zeros below (cpu.c:153-154)
-        if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
-        else if (g > pivprev) P[(size_t)(j - 1) * ldp + g] = 0.0;
     }
-    s_p[tid] = pval;
+    if (h == 1) { s_y[r] = yacc; s_pp[r] = pacc; }
     __syncthreads();
-    // rows past E contribute zero through s_p; V reads stay inside the padded buffer
-    block_gemv_t(V, ldp, g0, j, s_p, wpart + (size_t)blockIdx.x * ldw);
+    if (h == 0) {
+        double pval = 0.0;
+        if (g < E) {
+            double const tau = s_scal[1], beta = s_scal[2];
+            yacc += s_y[r]; pacc += s_pp[r];
+            double ysum = 0.0;
+            for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
+            double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
+            Y[(size_t)(j - 1) * ldp + g] = ynew;
+            pacc += ynew * s_vrow[j - 1];
+            pval = P[(size_t)j * ldp + g] - pacc;              // cpu.c:98-99
+            P[(size_t)j * ldp + g] = pval;
+            // column j-1 of P is final: beta on the sub-diagonal, zeros below (cpu.c:153-154)
+            if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
+            else if (g > pivprev) P[(size_t)(j - 1) * ldp + g] = 0.0;
+        }
+        s_p[r] = pval;
+    }
+    __syncthreads();
+    // w += VT(rows,0:j)^T p'   (rows past E contribute 0 through s_p)
+    block_gemv_t_atomic(VT, ldp, g0, j, s_p,
+        acc + ACC_WSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
 }
 
-// Last column of a panel: only finish Y(:,nb-1) and finalize P(:,nb-1).
+// After the last column of a panel: finish Y(:,nb-1) and finalize P(:,nb-1).
 __global__ __launch_bounds__(256)
 void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
-    double *__restrict__ P, double *__restrict__ Y,
-    double const *__restrict__ ypart, int nsplit,
-    double const *__restrict__ wv, double const *__restrict__ scal)
+    double *__restrict__ P, double const *__restrict__ V, double *__restrict__ Y,
+    double const *__restrict__ ypart, int nsplit, double const *__restrict__ acc,
+    double const *__restrict__ scal)
 {
-    __shared__ double s_wv[512];
+    __shared__ double s_wv[MAXJ], s_y[RB], s_scal[3];
     int const tid = threadIdx.x;
-    int const g = R0 + blockIdx.x * RB + tid;
-    int const pivprev = R0 + j - 1;
-    for (int l = tid; l < j - 1; l += 256) s_wv[l] = wv[l];
+    int const r = tid & (RB - 1), h = tid >> 7;
+    int const g = R0 + blockIdx.x * RB + r;
+    int const pivprev = R0 + j - 1, parp = (j - 1) & 1;
+    if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
     __syncthreads();
-    if (g < E) {
-        double const tau = scal[1], beta = scal[2];
+    for (int l = tid; l < j - 1; l += 256)
+        s_wv[l] = V[(size_t)l * ldp + pivprev]
+            + s_scal[0] * slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l);
+    __syncthreads();
+    double yacc = 0.0;
+    if (g < E)
+        for (int l = h; l < j - 1; l += 2) yacc += Y[(size_t)l * ldp + g] * s_wv[l];
+    if (h == 1) s_y[r] = yacc;
+    __syncthreads();
+    if (h == 0 && g < E) {
+        double const tau = s_scal[1], beta = s_scal[2];
+        yacc += s_y[r];
         double ysum = 0.0;
         for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
-        double yacc = 0.0;
-        for (int l = 0; l < j - 1; l++) yacc += Y[(size_t)l * ldp + g] * s_wv[l];
         Y[(size_t)(j - 1) * ldp + g] = tau * (ysum - yacc);
         if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
         else if (g > pivprev) P[(size_t)(j - 1) * ldp + g] = 0.0;
     }
 }
 
-// colB(j): w = TT * sum_wg wpart  (TT = T^T kept explicitly, lower triangular)
-__global__ __launch_bounds__(512)
-void hess_colB_kernel(int j, int nwg, double const *__restrict__ wpart, int ldw,
-    double const *__restrict__ TT, int ldt, double *__restrict__ w)
-{
-    __shared__ double s_w[512];
-    int const l = threadIdx.x;
-    if (l < j) {
-        double s = 0.0;
-        for (int b = 0; b < nwg; b++) s += wpart[(size_t)b * ldw + l];
-        s_w[l] = s;
-    }
-    __syncthreads();
-    if (l < j) {
-        double s = 0.0;
-        for (int r = 0; r <= l; r++) s += TT[(size_t)r * ldt + l] * s_w[r];   // T(r,l) w(r)
-        w[l] = s;
-    }
-}
-
-// colC(j): p'' = p' - V(:,0:j) w ; partial norm^2 below the pivot ; partial V^T p''(piv+1:)
+// colC(j): p'' = p' - V(:,0:j) w ; norm^2 below the pivot ; V^T p''(piv+1:)
 __global__ __launch_bounds__(256)
 void hess_colC_kernel(int R0, int E, int j, int ldp,
-    double *__restrict__ P, double const *__restrict__ V,
-    double const *__restrict__ w, double *__restrict__ normpart,
-    double *__restrict__ wvpart, int ldw)
+    double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc)
 {
-    __shared__ double s_w[512], s_p[RB], s_red[4];
+    __shared__ double s_w[MAXJ], s_p[RB], s_t[RB], s_red[2];
     int const tid = threadIdx.x;
+    int const r = tid & (RB - 1), h = tid >> 7;
     int const g0 = R0 + blockIdx.x * RB;
-    int const g = g0 + tid;
-    int const piv = R0 + j;
-    for (int l = tid; l < j; l += 256) s_w[l] = w[l];
+    int const g = g0 + r;
+    int const piv = R0 + j, par = j & 1;
+    for (int l = tid; l < j; l += 256)
+        s_w[l] = slot_sum(acc + ACC_WSUM + par * NSLOT * MAXJ, l);
+    if (blockIdx.x == 0)      // wsum of the other parity: read by colC(j-1), re-used by colA(j+1)
+        for (int l = tid; l < NSLOT * MAXJ; l += 256)
+            acc[ACC_WSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
     __syncthreads();
-    double pval = 0.0;
+    double a = 0.0;
     if (g < E) {
-        double acc = 0.0;
         double const *vrow = V + g;
-        int l = 0;
-        for (; l + 4 <= j; l += 4)
-            acc += vrow[(size_t)(l + 0) * ldp] * s_w[l] + vrow[(size_t)(l + 1) * ldp] * s_w[l + 1]
-                 + vrow[(size_t)(l + 2) * ldp] * s_w[l + 2] + vrow[(size_t)(l + 3) * ldp] * s_w[l + 3];
-        for (; l < j; l++) acc += vrow[(size_t)l * ldp] * s_w[l];
-        pval = P[(size_t)j * ldp + g];
-        if (j > 0) { pval -= acc; P[(size_t)j * ldp + g] = pval; }   // cpu.c:123-130
+        int l = h;
+        for (; l + 6 < j; l += 8)
+            a += vrow[(size_t)(l + 0) * ldp] * s_w[l] + vrow[(size_t)(l + 2) * ldp] * s_w[l + 2]
+               + vrow[(size_t)(l + 4) * ldp] * s_w[l + 4] + vrow[(size_t)(l + 6) * ldp] * s_w[l + 6];
+        for (; l < j; l += 2) a += vrow[(size_t)l * ldp] * s_w[l];
     }
-    double below = (g > piv && g < E) ? pval : 0.0;
-    s_p[tid] = below;
-    double ss = wave_sum(below * below);
-    if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+    if (h == 1) s_t[r] = a;
     __syncthreads();
-    if (tid == 0) normpart[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    block_gemv_t(V, ldp, g0, j, s_p, wvpart + (size_t)blockIdx.x * ldw);
-}
-
-// colD(j): reflector scalars (LAPACK dlarfg, cpu.c:137-141), w_v = V(piv:,0:j)^T v,
-// T(0:j,j) = -tau T(0:j,0:j) w_v, T(j,j) = tau (cpu.c:277-284).  One workgroup.
-__global__ __launch_bounds__(512)
-void hess_colD_kernel(int R0, int j, int ldp, int nwg,
-    double const *__restrict__ P, double const *__restrict__ V,
-    double const *__restrict__ normpart, double const *__restrict__ wvpart, int ldw,
-    double *__restrict__ T, double *__restrict__ TT, int ldt,
-    double *__restrict__ wv, double *__restrict__ scal)
-{
-    __shared__ double s_wv[512], s_red[8], s_scal[3];
-    int const tid = threadIdx.x;
-    int const piv = R0 + j;
-    double part = 0.0;
-    for (int b = tid; b < nwg; b += 512) part += normpart[b];
-    part = wave_sum(part);
-    if ((tid & 63) == 0) s_red[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0) {
-        double ssq = 0.0;
-        for (int k = 0; k < 8; k++) ssq += s_red[k];
-        double alpha = P[(size_t)j * ldp + piv];
-        double xnorm = sqrt(ssq);
-        double tau = 0.0, scale = 0.0, beta = alpha;
-        if (xnorm != 0.0) {
-            beta = -copysign(hypot(alpha, xnorm), alpha);
-            tau = (beta - alpha) / beta;
-            scale = 1.0 / (alpha - beta);
+    double below = 0.0;
+    if (h == 0) {
+        if (g < E) {
+            double pval = P[(size_t)j * ldp + g];
+            if (j > 0) { pval -= a + s_t[r]; P[(size_t)j * ldp + g] = pval; }   // cpu.c:123-130
+            if (g > piv) below = pval;
         }
-        s_scal[0] = scale; s_scal[1] = tau; s_scal[2] = beta;
-        scal[0] = scale; scal[1] = tau; scal[2] = beta;
+        s_p[r] = below;
+        double ss = wave_sum(below * below);
+        if ((tid & 63) == 0) s_red[tid >> 6] = ss;
     }
     __syncthreads();
-    double const scale = s_scal[0], tau = s_scal[1];
-    if (tid < j) {
-        double s = 0.0;
-        for (int b = 0; b < nwg; b++) s += wvpart[(size_t)b * ldw + tid];
-        double x = V[(size_t)tid * ldp + piv] + scale * s;     // v(piv) = 1
-        s_wv[tid] = x;
-        wv[tid] = x;
-    }
-    __syncthreads();
-    if (tid < j) {
-        double s = 0.0;
-        for (int r = tid; r < j; r++) s += T[(size_t)r * ldt + tid] * s_wv[r];
-        s *= -tau;
-        T[(size_t)j * ldt + tid] = s;
-        TT[(size_t)tid * ldt + j] = s;
-    }
-    if (tid == 0) { T[(size_t)j * ldt + j] = tau; TT[(size_t)j * ldt + j] = tau; }
+    if (tid == 0)
+        atomicAdd(acc + ACC_NRM + par * NSLOT + (blockIdx.x & (NSLOT - 1)), s_red[0] + s_red[1]);
+    block_gemv_t_atomic(V, ldp, g0, j, s_p,
+        acc + ACC_WVSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
 }
 
 // The big gemv: ypart[split][g] = sum_{c in split} A[g, c] * v[c],  g in [R0,E),
-// c in [piv,E), v[piv] = 1, v[c] = scale * p''[c].  Also materialises V(:,j).
+// c in [piv,E), v[piv] = 1, v[c] = scale * p''[c].
 // Workgroup = 512 rows (each lane owns an aligned row pair, 16-byte loads) x one
 // column chunk; the 4 waves of a workgroup read 4 KiB contiguous per column.
-template <int UNROLL>
+// blockIdx.y == 0 : the "shadow" blocks -- V(:,j) = v, VT(:,j) = tau (v - VT w_v),
+//                   and (block 0) reset of the accumulators of the other parity.
+// blockIdx.y >= 1 : column chunk blockIdx.y-1 of the gemv.
+template <int UNROLL, bool ALIGNED>
 __global__ __launch_bounds__(256)
 void hess_gemv_kernel(double const *__restrict__ A, int ldA,
-    double const *__restrict__ pcol, double const *__restrict__ scal,
-    int R0, int E, int piv, int cols_per_split, int ldp,
-    double *__restrict__ ypart, double *__restrict__ Vcol)
+    double const *__restrict__ P, int R0, int E, int j, int cols_per_split, int ldp,
+    double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
+    double *__restrict__ acc, double *__restrict__ scal)
 {
-    int const g = (R0 & ~1) + blockIdx.x * GEMV_ROWS + threadIdx.x * 2;
-    int const c_begin = piv + blockIdx.y * cols_per_split;
+    __shared__ double s_wv[MAXJ], s_scal[2];
+    int const piv = R0 + j, par = j & 1;
+    double const *__restrict__ pcol = P + (size_t)j * ldp;
+    if (threadIdx.x == 0) {
+        double scale, tau, beta;
+        reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+        s_scal[0] = scale; s_scal[1] = tau;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {   // published for colA(j+1) / finish
+            scal[4 * j + 0] = scale; scal[4 * j + 1] = tau; scal[4 * j + 2] = beta;
+        }
+    }
+    __syncthreads();
+    double const scale = s_scal[0];
+
+    if (blockIdx.y == 0) {
+        double const tau = s_scal[1];
+        for (int l = threadIdx.x; l < j; l += 256)
+            s_wv[l] = V[(size_t)l * ldp + piv]
+                + scale * slot_sum(acc + ACC_WVSUM + par * NSLOT * MAXJ, l);
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            for (int l = threadIdx.x; l < NSLOT * MAXJ; l += 256)
+                acc[ACC_WVSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
+            if (threadIdx.x < NSLOT) acc[ACC_NRM + (par ^ 1) * NSLOT + threadIdx.x] = 0.0;
+        }
+        for (int q = 0; q < 2; q++) {
+            int const g = R0 + blockIdx.x * GEMV_ROWS + q * 256 + threadIdx.x;
+            if (g >= E) continue;
+            double v = g < piv ? 0.0 : (g == piv ? 1.0 : scale * pcol[g]);
+            V[(size_t)j * ldp + g] = v;
+            double a0 = 0.0, a1 = 0.0;
+            double const *row = VT + g;
+            int l = 0;
+            for (; l + 4 <= j; l += 4) {
+                a0 += row[(size_t)(l + 0) * ldp] * s_wv[l] + row[(size_t)(l + 2) * ldp] * s_wv[l + 2];
+                a1 += row[(size_t)(l + 1) * ldp] * s_wv[l + 1] + row[(size_t)(l + 3) * ldp] * s_wv[l + 3];
+            }
+            for (; l < j; l++) a0 += row[(size_t)l * ldp] * s_wv[l];
+            VT[(size_t)j * ldp + g] = tau * (v - (a0 + a1));
+        }
+        return;
+    }
+
+    int const split = blockIdx.y - 1;
+    int const c_begin = piv + split * cols_per_split;
     int const c_end = min(E, c_begin + cols_per_split);
-    double const scale = scal[0];
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-    if (g < E) {
+    double *yp = ypart + (size_t)split * ldp;
+    if (ALIGNED) {
+        int const g = (R0 & ~1) + blockIdx.x * GEMV_ROWS + threadIdx.x * 2;
+        if (g >= E) return;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
         double const *a = A + (size_t)c_begin * ldA + g;
         int c = c_begin;
         for (; c + UNROLL <= c_end; c += UNROLL) {
@@ -295,40 +348,19 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             a0 += x.x * v0; a1 += x.y * v0;
             a += ldA;
         }
-        double *yp = ypart + (size_t)blockIdx.y * ldp;
         if (g >= R0) yp[g] = a0 + b0;
         if (g + 1 < E) yp[g + 1] = a1 + b1;
-        if (blockIdx.y == 0) {
-            #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                int gg = g + q;
-                if (gg >= R0 && gg < E)
-                    Vcol[gg] = gg < piv ? 0.0 : (gg == piv ? 1.0 : scale * pcol[gg]);
-            }
+    } else {
+        // odd leading dimension / unaligned base: 8-byte loads
+        for (int q = 0; q < 2; q++) {
+            int const g = R0 + blockIdx.x * GEMV_ROWS + q * 256 + threadIdx.x;
+            if (g >= E) continue;
+            double s = 0.0;
+            double const *a = A + (size_t)c_begin * ldA + g;
+            for (int c = c_begin; c < c_end; c++, a += ldA)
+                s += (*a) * ((c == piv) ? 1.0 : scale * pcol[c]);
+            yp[g] = s;
         }
-    }
-}
-
-// Fallback for odd leading dimensions / unaligned bases (8-byte loads).
-__global__ __launch_bounds__(256)
-void hess_gemv_unaligned_kernel(double const *__restrict__ A, int ldA,
-    double const *__restrict__ pcol, double const *__restrict__ scal,
-    int R0, int E, int piv, int cols_per_split, int ldp,
-    double *__restrict__ ypart, double *__restrict__ Vcol)
-{
-    int const c_begin = piv + blockIdx.y * cols_per_split;
-    int const c_end = min(E, c_begin + cols_per_split);
-    double const scale = scal[0];
-    for (int q = 0; q < 2; q++) {
-        int const g = R0 + blockIdx.x * GEMV_ROWS + q * 256 + threadIdx.x;
-        if (g >= E) continue;
-        double acc = 0.0;
-        double const *a = A + (size_t)c_begin * ldA + g;
-        for (int c = c_begin; c < c_end; c++, a += ldA)
-            acc += (*a) * ((c == piv) ? 1.0 : scale * pcol[c]);
-        ypart[(size_t)blockIdx.y * ldp + g] = acc;
-        if (blockIdx.y == 0)
-            Vcol[g] = g < piv ? 0.0 : (g == piv ? 1.0 : scale * pcol[g]);
     }
 }
 
@@ -349,12 +381,10 @@ __global__ void hess_copy_out_kernel(int R0, int E, int nb, int i,
 
 // ---- workspace ----------------------------------------------------------------
 struct HessWorkspace {
-    int n = 0, nbmax = 0, ldp = 0, ldw = 0, nwg_max = 0;
+    int n = 0, nbmax = 0, ldp = 0;
     double *P = nullptr, *V[2] = {nullptr, nullptr}, *Y = nullptr, *VT[2] = {nullptr, nullptr};
-    double *T[2] = {nullptr, nullptr}, *TT = nullptr;
     double *W = nullptr, *W2 = nullptr;
-    double *ypart = nullptr, *wpart = nullptr, *wvpart = nullptr, *normpart = nullptr;
-    double *w = nullptr, *wv = nullptr, *scal = nullptr;
+    double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t panel_done[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -362,8 +392,7 @@ struct HessWorkspace {
     std::vector<double> sample_bytes;
 
     void release() {
-        double **ptrs[] = {&P, &V[0], &V[1], &Y, &VT[0], &VT[1], &T[0], &T[1], &TT, &W, &W2,
-            &ypart, &wpart, &wvpart, &normpart, &w, &wv, &scal};
+        double **ptrs[] = {&P, &V[0], &V[1], &Y, &VT[0], &VT[1], &W, &W2, &ypart, &acc, &scal};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = nbmax = 0;
     }
@@ -371,9 +400,7 @@ struct HessWorkspace {
         if (n_ <= n && nb_ <= nbmax) return;
         release();
         n = n_; nbmax = nb_;
-        ldp = (int)roundup((size_t)n + RB + 16, 128);
-        ldw = (int)roundup((size_t)nbmax, 16);
-        nwg_max = divceil(n, RB) + 1;
+        ldp = (int)roundup((size_t)n + GEMV_ROWS + 16, 128);
         size_t pan = (size_t)ldp * nbmax * sizeof(double);
         auto alloc = [](double **p, size_t bytes) {
             SN_HIP_CHECK(hipMalloc((void **)p, bytes));
@@ -381,15 +408,10 @@ struct HessWorkspace {
         };
         alloc(&P, pan); alloc(&V[0], pan); alloc(&V[1], pan); alloc(&Y, pan);
         alloc(&VT[0], pan); alloc(&VT[1], pan);
-        size_t tb = (size_t)nbmax * nbmax * sizeof(double);
-        alloc(&T[0], tb); alloc(&T[1], tb); alloc(&TT, tb);
         alloc(&W, pan); alloc(&W2, pan);
         alloc(&ypart, (size_t)MAX_SPLIT * ldp * sizeof(double));
-        alloc(&wpart, (size_t)nwg_max * ldw * sizeof(double));
-        alloc(&wvpart, (size_t)nwg_max * ldw * sizeof(double));
-        alloc(&normpart, (size_t)nwg_max * sizeof(double));
-        alloc(&w, 512 * sizeof(double)); alloc(&wv, 512 * sizeof(double));
-        alloc(&scal, 16 * sizeof(double));
+        alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
+        alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
         if (!side) {
             SN_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             for (int k = 0; k < 2; k++) {
@@ -421,10 +443,10 @@ static void choose_split(int m_rows, int ncols, int *nsplit, int *cps)
 int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *tm)
 {
-    if (panel_width > 504) panel_width = 504;           // column kernels hold j <= 512 in LDS
+    if (panel_width > MAXJ - 8) panel_width = MAXJ - 8;   // column kernels hold j < MAXJ in LDS
     HessWorkspace &ws = g_ws;
     ws.ensure(n, panel_width);
-    int const ldp = ws.ldp, ldw = ws.ldw;
+    int const ldp = ws.ldp;
     bool const aligned = (ldA % 2 == 0) && (((uintptr_t)dA) % 16 == 0);
     double gemv_bytes = 0.0, gemm_flops = 0.0;
     long gemv_launches = 0;
@@ -438,35 +460,26 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
         int const nb = std::min(panel_width, end - i - 1);
         int const R0 = i + 1, E = end, m = E - R0;
         int const buf = pcount & 1;
-        double *V = ws.V[buf], *VT = ws.VT[buf], *T = ws.T[buf];
+        double *V = ws.V[buf], *VT = ws.VT[buf];
         int const nwg = divceil(m, RB);
 
-        // V/VT/T of this slot were last used by the side stream two panels ago
+        // V/VT of this slot were last used by the side stream two panels ago
         if (pcount >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.side_done[buf], 0));
 
-        SN_HIP_CHECK(hipMemsetAsync(T, 0, (size_t)ws.nbmax * ws.nbmax * sizeof(double), s));
-        SN_HIP_CHECK(hipMemsetAsync(ws.TT, 0, (size_t)ws.nbmax * ws.nbmax * sizeof(double), s));
+        SN_HIP_CHECK(hipMemsetAsync(ws.acc, 0, (size_t)ACC_TOTAL * sizeof(double), s));
         hipLaunchKernelGGL(hess_copy_in_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, ws.P, ldp);                                // core.c:451
 
         int nsplit = 1, cps = 0;
         for (int j = 0; j < nb; j++) {
             int const piv = R0 + j;
-            if (j > 0) {
+            if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(256), 0, s,
-                    R0, E, j, ldp, ws.P, V, ws.Y, ws.ypart, nsplit, ws.wv, ws.scal,
-                    ws.wpart, ldw);
-                hipLaunchKernelGGL(hess_colB_kernel, dim3(1), dim3(512), 0, s,
-                    j, nwg, ws.wpart, ldw, ws.TT, ws.nbmax, ws.w);
-            }
+                    R0, E, j, ldp, ws.P, V, VT, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(256), 0, s,
-                R0, E, j, ldp, ws.P, V, ws.w, ws.normpart, ws.wvpart, ldw);
-            hipLaunchKernelGGL(hess_colD_kernel, dim3(1), dim3(512), 0, s,
-                R0, j, ldp, nwg, ws.P, V, ws.normpart, ws.wvpart, ldw,
-                T, ws.TT, ws.nbmax, ws.wv, ws.scal);
+                R0, E, j, ldp, ws.P, V, ws.acc);
             int const ncols = E - piv;
             choose_split(m, ncols, &nsplit, &cps);
-            dim3 grid(divceil(E - (R0 & ~1), GEMV_ROWS), nsplit);
             bool const sampled = sample_every > 0 && (gemv_launches % sample_every) == 0;
             if (sampled) {
                 if (ws.sample_ev.size() < 2 * (nsampled + 1)) {
@@ -477,15 +490,13 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
                 }
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled], s));
             }
+            dim3 grid(divceil(E - (R0 & ~1), GEMV_ROWS), nsplit + 1);
             if (aligned)
-                hipLaunchKernelGGL(hess_gemv_kernel<8>, grid, dim3(256), 0, s,
-                    dA, ldA, ws.P + (size_t)j * ldp, ws.scal, R0, E, piv, cps, ldp,
-                    ws.ypart, V + (size_t)j * ldp);
+                hipLaunchKernelGGL((hess_gemv_kernel<8, true>), grid, dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, ws.ypart, V, VT, ws.acc, ws.scal);
             else
-                hipLaunchKernelGGL(hess_gemv_unaligned_kernel,
-                    dim3(divceil(m, GEMV_ROWS), nsplit), dim3(256), 0, s,
-                    dA, ldA, ws.P + (size_t)j * ldp, ws.scal, R0, E, piv, cps, ldp,
-                    ws.ypart, V + (size_t)j * ldp);
+                hipLaunchKernelGGL((hess_gemv_kernel<8, false>), grid, dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, ws.ypart, V, VT, ws.acc, ws.scal);
             if (sampled) {
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
                 ws.sample_bytes.push_back(8.0 * (double)m * (double)ncols);
@@ -495,13 +506,9 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
             gemv_bytes += 8.0 * (double)m * (double)ncols;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(256), 0, s,
-            R0, E, nb, ldp, ws.P, ws.Y, ws.ypart, nsplit, ws.wv, ws.scal);
+            R0, E, nb, ldp, ws.P, V, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
 
-        // VT = V * T  (so that every W = X^T/X * V * T below is one GEMM)
-        dgemm(s, 'N', 'N', m, nb, nb, 1.0, V + R0, ldp, T, ws.nbmax, 0.0, VT + R0, ldp);
-        gemm_flops += 2.0 * m * nb * nb;
-
-        // ---- critical trailing updates (core.c:523-547) ----
+        // ---- critical trailing updates (core.c:523-547); VT = V*T comes from the panel ----
         int const nt = E - (i + nb);
         if (nt > 0) {
             double *At = dA + (size_t)(i + nb) * ldA + R0;
