@@ -138,8 +138,8 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     SN_HIP_CHECK(hipMalloc((void **)&dA, bytes));
     SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
     if (g_node.pinning) {
-        hipHostRegister(A, (size_t)ldA * n * sizeof(double), hipHostRegisterDefault);
-        hipHostRegister(Q, (size_t)ldQ * n * sizeof(double), hipHostRegisterDefault);
+        (void)hipHostRegister(A, (size_t)ldA * n * sizeof(double), hipHostRegisterDefault);
+        (void)hipHostRegister(Q, (size_t)ldQ * n * sizeof(double), hipHostRegisterDefault);
     }
     SN_HIP_CHECK(hipMemset(dA, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
@@ -155,7 +155,7 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
         hipMemcpyDeviceToHost));
     SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n,
         hipMemcpyDeviceToHost));
-    if (g_node.pinning) { hipHostUnregister(A); hipHostUnregister(Q); }
+    if (g_node.pinning) { (void)hipHostUnregister(A); (void)hipHostUnregister(Q); }
     SN_HIP_CHECK(hipFree(dA));
     SN_HIP_CHECK(hipFree(dQ));
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;

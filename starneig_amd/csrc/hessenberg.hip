@@ -54,7 +54,9 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-constexpr int RB = 128;          // rows per workgroup in the row-parallel column kernels
+constexpr int RB = 64;           // rows per workgroup in the row-parallel column kernels
+constexpr int NG = 4;            // column groups (= waves) sharing one row in those kernels
+constexpr int RBS = 16, NGS = 16; // rows / column groups of a shadow block inside the gemv launch
 constexpr int GEMV_ROWS = 512;   // rows per workgroup of the big gemv (4 waves x 64 lanes x 2)
 constexpr int MAX_SPLIT = 32;
 constexpr int NSLOT = 8;         // atomic accumulator slots (spreads same-address contention)
@@ -119,9 +121,9 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
     double *__restrict__ acc, double const *__restrict__ scal)
 {
-    __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_p[RB], s_y[RB], s_pp[RB], s_scal[3];
+    __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_p[RB], s_y[NG - 1][RB], s_pp[NG - 1][RB], s_scal[3];
     int const tid = threadIdx.x;
-    int const r = tid & (RB - 1), h = tid >> 7;
+    int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
     int const pivprev = R0 + j - 1, parp = (j - 1) & 1, par = j & 1;
@@ -143,25 +145,26 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     if (g < E) {
         double const *yrow = Y + g;
         int l = h;
-        for (; l + 6 < j - 1; l += 8) {
-            double y0 = yrow[(size_t)(l + 0) * ldp], y1 = yrow[(size_t)(l + 2) * ldp];
-            double y2 = yrow[(size_t)(l + 4) * ldp], y3 = yrow[(size_t)(l + 6) * ldp];
-            yacc += y0 * s_wv[l] + y1 * s_wv[l + 2] + y2 * s_wv[l + 4] + y3 * s_wv[l + 6];
-            pacc += y0 * s_vrow[l] + y1 * s_vrow[l + 2] + y2 * s_vrow[l + 4] + y3 * s_vrow[l + 6];
+        for (; l + 3 * NG < j - 1; l += 4 * NG) {
+            double y0 = yrow[(size_t)(l + 0 * NG) * ldp], y1 = yrow[(size_t)(l + 1 * NG) * ldp];
+            double y2 = yrow[(size_t)(l + 2 * NG) * ldp], y3 = yrow[(size_t)(l + 3 * NG) * ldp];
+            yacc += y0 * s_wv[l] + y1 * s_wv[l + NG] + y2 * s_wv[l + 2 * NG] + y3 * s_wv[l + 3 * NG];
+            pacc += y0 * s_vrow[l] + y1 * s_vrow[l + NG] + y2 * s_vrow[l + 2 * NG] + y3 * s_vrow[l + 3 * NG];
         }
-        for (; l < j - 1; l += 2) {
+        for (; l < j - 1; l += NG) {
             double y0 = yrow[(size_t)l * ldp];
             yacc += y0 * s_wv[l];
             pacc += y0 * s_vrow[l];
         }
     }
-    if (h == 1) { s_y[r] = yacc; s_pp[r] = pacc; }
+    if (h > 0) { s_y[h - 1][r] = yacc; s_pp[h - 1][r] = pacc; }
     __syncthreads();
     if (h == 0) {
         double pval = 0.0;
         if (g < E) {
             double const tau = s_scal[1], beta = s_scal[2];
-            yacc += s_y[r]; pacc += s_pp[r];
+            #pragma unroll
+            for (int q = 0; q < NG - 1; q++) { yacc += s_y[q][r]; pacc += s_pp[q][r]; }
             double ysum = 0.0;
             for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
             double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
@@ -188,9 +191,9 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     double const *__restrict__ ypart, int nsplit, double const *__restrict__ acc,
     double const *__restrict__ scal)
 {
-    __shared__ double s_wv[MAXJ], s_y[RB], s_scal[3];
+    __shared__ double s_wv[MAXJ], s_y[NG - 1][RB], s_scal[3];
     int const tid = threadIdx.x;
-    int const r = tid & (RB - 1), h = tid >> 7;
+    int const r = tid & (RB - 1), h = tid >> 6;
     int const g = R0 + blockIdx.x * RB + r;
     int const pivprev = R0 + j - 1, parp = (j - 1) & 1;
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
@@ -201,12 +204,13 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     __syncthreads();
     double yacc = 0.0;
     if (g < E)
-        for (int l = h; l < j - 1; l += 2) yacc += Y[(size_t)l * ldp + g] * s_wv[l];
-    if (h == 1) s_y[r] = yacc;
+        for (int l = h; l < j - 1; l += NG) yacc += Y[(size_t)l * ldp + g] * s_wv[l];
+    if (h > 0) s_y[h - 1][r] = yacc;
     __syncthreads();
     if (h == 0 && g < E) {
         double const tau = s_scal[1], beta = s_scal[2];
-        yacc += s_y[r];
+        #pragma unroll
+        for (int q = 0; q < NG - 1; q++) yacc += s_y[q][r];
         double ysum = 0.0;
         for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
         Y[(size_t)(j - 1) * ldp + g] = tau * (ysum - yacc);
@@ -220,9 +224,9 @@ __global__ __launch_bounds__(256)
 void hess_colC_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc)
 {
-    __shared__ double s_w[MAXJ], s_p[RB], s_t[RB], s_red[2];
+    __shared__ double s_w[MAXJ], s_p[RB], s_t[NG - 1][RB];
     int const tid = threadIdx.x;
-    int const r = tid & (RB - 1), h = tid >> 7;
+    int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
     int const piv = R0 + j, par = j & 1;
@@ -236,94 +240,110 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
     if (g < E) {
         double const *vrow = V + g;
         int l = h;
-        for (; l + 6 < j; l += 8)
-            a += vrow[(size_t)(l + 0) * ldp] * s_w[l] + vrow[(size_t)(l + 2) * ldp] * s_w[l + 2]
-               + vrow[(size_t)(l + 4) * ldp] * s_w[l + 4] + vrow[(size_t)(l + 6) * ldp] * s_w[l + 6];
-        for (; l < j; l += 2) a += vrow[(size_t)l * ldp] * s_w[l];
+        for (; l + 3 * NG < j; l += 4 * NG)
+            a += vrow[(size_t)(l + 0 * NG) * ldp] * s_w[l] + vrow[(size_t)(l + 1 * NG) * ldp] * s_w[l + NG]
+               + vrow[(size_t)(l + 2 * NG) * ldp] * s_w[l + 2 * NG] + vrow[(size_t)(l + 3 * NG) * ldp] * s_w[l + 3 * NG];
+        for (; l < j; l += NG) a += vrow[(size_t)l * ldp] * s_w[l];
     }
-    if (h == 1) s_t[r] = a;
+    if (h > 0) s_t[h - 1][r] = a;
     __syncthreads();
-    double below = 0.0;
     if (h == 0) {
+        double below = 0.0;
         if (g < E) {
             double pval = P[(size_t)j * ldp + g];
-            if (j > 0) { pval -= a + s_t[r]; P[(size_t)j * ldp + g] = pval; }   // cpu.c:123-130
+            if (j > 0) {                                                    // cpu.c:123-130
+                #pragma unroll
+                for (int q = 0; q < NG - 1; q++) a += s_t[q][r];
+                pval -= a;
+                P[(size_t)j * ldp + g] = pval;
+            }
             if (g > piv) below = pval;
         }
         s_p[r] = below;
         double ss = wave_sum(below * below);
-        if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+        if (tid == 0)
+            atomicAdd(acc + ACC_NRM + par * NSLOT + (blockIdx.x & (NSLOT - 1)), ss);
     }
     __syncthreads();
-    if (tid == 0)
-        atomicAdd(acc + ACC_NRM + par * NSLOT + (blockIdx.x & (NSLOT - 1)), s_red[0] + s_red[1]);
     block_gemv_t_atomic(V, ldp, g0, j, s_p,
         acc + ACC_WVSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
 }
 
 // The big gemv: ypart[split][g] = sum_{c in split} A[g, c] * v[c],  g in [R0,E),
 // c in [piv,E), v[piv] = 1, v[c] = scale * p''[c].
-// Workgroup = 512 rows (each lane owns an aligned row pair, 16-byte loads) x one
-// column chunk; the 4 waves of a workgroup read 4 KiB contiguous per column.
-// blockIdx.y == 0 : the "shadow" blocks -- V(:,j) = v, VT(:,j) = tau (v - VT w_v),
-//                   and (block 0) reset of the accumulators of the other parity.
-// blockIdx.y >= 1 : column chunk blockIdx.y-1 of the gemv.
+// One launch, 1-D grid:
+//   blocks [0, nshadow)  : the "shadow" blocks (64 rows each) -- V(:,j) = v and
+//                          VT(:,j) = tau (v - VT w_v); block 0 also resets the
+//                          accumulators of the other parity and publishes the scalars.
+//   remaining blocks     : gemv tiles, 512 rows (each lane owns an aligned row pair,
+//                          16-byte non-temporal loads: A is streamed once per column)
+//                          x one column chunk; the 4 waves of a workgroup read 4 KiB
+//                          contiguous per column.
 template <int UNROLL, bool ALIGNED>
 __global__ __launch_bounds__(256)
 void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double const *__restrict__ P, int R0, int E, int j, int cols_per_split, int ldp,
+    int nshadow, int row_tiles,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
     double *__restrict__ acc, double *__restrict__ scal)
 {
-    __shared__ double s_wv[MAXJ], s_scal[2];
+    __shared__ double s_wv[MAXJ], s_t[NGS][RBS + 1], s_scal[2];
     int const piv = R0 + j, par = j & 1;
     double const *__restrict__ pcol = P + (size_t)j * ldp;
     if (threadIdx.x == 0) {
         double scale, tau, beta;
         reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
         s_scal[0] = scale; s_scal[1] = tau;
-        if (blockIdx.x == 0 && blockIdx.y == 0) {   // published for colA(j+1) / finish
+        if (blockIdx.x == 0) {   // published for colA(j+1) / finish
             scal[4 * j + 0] = scale; scal[4 * j + 1] = tau; scal[4 * j + 2] = beta;
         }
     }
     __syncthreads();
     double const scale = s_scal[0];
 
-    if (blockIdx.y == 0) {
+    if ((int)blockIdx.x < nshadow) {
         double const tau = s_scal[1];
-        for (int l = threadIdx.x; l < j; l += 256)
+        int const tid = threadIdx.x;
+        int const r = tid & (RBS - 1), h = tid / RBS;
+        int const g = R0 + blockIdx.x * RBS + r;
+        for (int l = tid; l < j; l += 256)
             s_wv[l] = V[(size_t)l * ldp + piv]
                 + scale * slot_sum(acc + ACC_WVSUM + par * NSLOT * MAXJ, l);
         __syncthreads();
         if (blockIdx.x == 0) {
-            for (int l = threadIdx.x; l < NSLOT * MAXJ; l += 256)
+            for (int l = tid; l < NSLOT * MAXJ; l += 256)
                 acc[ACC_WVSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
-            if (threadIdx.x < NSLOT) acc[ACC_NRM + (par ^ 1) * NSLOT + threadIdx.x] = 0.0;
+            if (tid < NSLOT) acc[ACC_NRM + (par ^ 1) * NSLOT + tid] = 0.0;
         }
-        for (int q = 0; q < 2; q++) {
-            int const g = R0 + blockIdx.x * GEMV_ROWS + q * 256 + threadIdx.x;
-            if (g >= E) continue;
+        double a = 0.0;
+        if (g < E) {
+            double const *row = VT + g;
+            int l = h;
+            for (; l + 3 * NGS < j; l += 4 * NGS)
+                a += row[(size_t)(l + 0 * NGS) * ldp] * s_wv[l] + row[(size_t)(l + 1 * NGS) * ldp] * s_wv[l + NGS]
+                   + row[(size_t)(l + 2 * NGS) * ldp] * s_wv[l + 2 * NGS] + row[(size_t)(l + 3 * NGS) * ldp] * s_wv[l + 3 * NGS];
+            for (; l < j; l += NGS) a += row[(size_t)l * ldp] * s_wv[l];
+        }
+        s_t[h][r] = a;
+        __syncthreads();
+        if (h == 0 && g < E) {
+            a = 0.0;
+            #pragma unroll
+            for (int q = 0; q < NGS; q++) a += s_t[q][r];
             double v = g < piv ? 0.0 : (g == piv ? 1.0 : scale * pcol[g]);
             V[(size_t)j * ldp + g] = v;
-            double a0 = 0.0, a1 = 0.0;
-            double const *row = VT + g;
-            int l = 0;
-            for (; l + 4 <= j; l += 4) {
-                a0 += row[(size_t)(l + 0) * ldp] * s_wv[l] + row[(size_t)(l + 2) * ldp] * s_wv[l + 2];
-                a1 += row[(size_t)(l + 1) * ldp] * s_wv[l + 1] + row[(size_t)(l + 3) * ldp] * s_wv[l + 3];
-            }
-            for (; l < j; l++) a0 += row[(size_t)l * ldp] * s_wv[l];
-            VT[(size_t)j * ldp + g] = tau * (v - (a0 + a1));
+            VT[(size_t)j * ldp + g] = tau * (v - a);
         }
         return;
     }
 
-    int const split = blockIdx.y - 1;
+    int const b = blockIdx.x - nshadow;
+    int const tile = b % row_tiles, split = b / row_tiles;
     int const c_begin = piv + split * cols_per_split;
     int const c_end = min(E, c_begin + cols_per_split);
     double *yp = ypart + (size_t)split * ldp;
     if (ALIGNED) {
-        int const g = (R0 & ~1) + blockIdx.x * GEMV_ROWS + threadIdx.x * 2;
+        int const g = (R0 & ~1) + tile * GEMV_ROWS + threadIdx.x * 2;
         if (g >= E) return;
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
         double const *a = A + (size_t)c_begin * ldA + g;
@@ -332,7 +352,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             d2 x[UNROLL];
             #pragma unroll
             for (int u = 0; u < UNROLL; u++)
-                x[u] = *reinterpret_cast<d2 const *>(a + (size_t)u * ldA);
+                x[u] = __builtin_nontemporal_load(reinterpret_cast<d2 const *>(a + (size_t)u * ldA));
             #pragma unroll
             for (int u = 0; u < UNROLL; u += 2) {
                 double v0 = (c + u == piv) ? 1.0 : scale * pcol[c + u];
@@ -343,7 +363,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             a += (size_t)UNROLL * ldA;
         }
         for (; c < c_end; c++) {
-            d2 x = *reinterpret_cast<d2 const *>(a);
+            d2 x = __builtin_nontemporal_load(reinterpret_cast<d2 const *>(a));
             double v0 = (c == piv) ? 1.0 : scale * pcol[c];
             a0 += x.x * v0; a1 += x.y * v0;
             a += ldA;
@@ -353,7 +373,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     } else {
         // odd leading dimension / unaligned base: 8-byte loads
         for (int q = 0; q < 2; q++) {
-            int const g = R0 + blockIdx.x * GEMV_ROWS + q * 256 + threadIdx.x;
+            int const g = R0 + tile * GEMV_ROWS + q * 256 + threadIdx.x;
             if (g >= E) continue;
             double s = 0.0;
             double const *a = A + (size_t)c_begin * ldA + g;
@@ -385,7 +405,8 @@ struct HessWorkspace {
     double *P = nullptr, *V[2] = {nullptr, nullptr}, *Y = nullptr, *VT[2] = {nullptr, nullptr};
     double *W = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, main = nullptr;
+    hipEvent_t entry = nullptr;
     hipEvent_t panel_done[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> sample_ev;      // pairs (start, stop) around sampled gemv launches
@@ -413,7 +434,12 @@ struct HessWorkspace {
         alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
         alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
         if (!side) {
-            SN_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            int lo = 0, hi = 0;
+            SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest
+            // the latency-critical panel chain outranks the bulk GEMM updates
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, hi));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
+            SN_HIP_CHECK(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
             for (int k = 0; k < 2; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&panel_done[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&side_done[k], hipEventDisableTiming));
@@ -431,16 +457,16 @@ void hessenberg_release_workspace() { g_ws.release(); }
 static void choose_split(int m_rows, int ncols, int *nsplit, int *cps)
 {
     int row_tiles = divceil(m_rows + 1, GEMV_ROWS);
-    int want = std::max(1, 1536 / row_tiles);           // ~6 workgroups per CU
+    int want = std::max(1, 1280 / row_tiles);           // ~5 workgroups per CU (measured optimum)
     int s = std::min({want, MAX_SPLIT, std::max(1, ncols / 16)});
     int c = divceil(ncols, s);
-    c = (c + 7) / 8 * 8;
+    c = (c + 15) / 16 * 16;
     s = divceil(ncols, c);
     *nsplit = std::max(1, s);
     *cps = c;
 }
 
-int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
+int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *tm)
 {
     if (panel_width > MAXJ - 8) panel_width = MAXJ - 8;   // column kernels hold j < MAXJ in LDS
@@ -454,6 +480,10 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     int const sample_every = tm ? tm->sample_every : 0;
     ws.sample_bytes.clear();
 
+    // everything runs on the library's own streams, fenced against the caller's stream
+    hipStream_t s = ws.main;
+    SN_HIP_CHECK(hipEventRecord(ws.entry, caller));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, ws.entry, 0));
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
     int pcount = 0;
     for (int i = begin; i < end - 1; i += panel_width, pcount++) {
@@ -490,13 +520,15 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
                 }
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled], s));
             }
-            dim3 grid(divceil(E - (R0 & ~1), GEMV_ROWS), nsplit + 1);
+            int const row_tiles = divceil(E - (R0 & ~1), GEMV_ROWS);
+            int const nshadow = divceil(m, RBS);
+            dim3 grid(nshadow + row_tiles * nsplit);
             if (aligned)
-                hipLaunchKernelGGL((hess_gemv_kernel<8, true>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, ws.ypart, V, VT, ws.acc, ws.scal);
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal);
             else
-                hipLaunchKernelGGL((hess_gemv_kernel<8, false>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, ws.ypart, V, VT, ws.acc, ws.scal);
+                hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal);
             if (sampled) {
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
                 ws.sample_bytes.push_back(8.0 * (double)m * (double)ncols);
@@ -549,8 +581,9 @@ int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     // join the side stream back into s
     for (int k = 0; k < 2 && k < pcount; k++)
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.side_done[k], 0));
+    SN_HIP_CHECK(hipEventRecord(ws.ev1, s));
+    SN_HIP_CHECK(hipStreamWaitEvent(caller, ws.ev1, 0));
     if (tm) {
-        SN_HIP_CHECK(hipEventRecord(ws.ev1, s));
         SN_HIP_CHECK(hipEventSynchronize(ws.ev1));
         float ms = 0.f;
         SN_HIP_CHECK(hipEventElapsedTime(&ms, ws.ev0, ws.ev1));
