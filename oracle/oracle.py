@@ -46,6 +46,11 @@ def lib():
         L.oracle_count_below_subdiagonal.restype = C.c_long
         L.oracle_dlarfg.argtypes = [C.c_int, dp, dp]
         L.oracle_dlarfg.restype = C.c_double
+        L.oracle_schur.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, dp]
+        L.oracle_schur.restype = C.c_int
+        L.oracle_extract_eigenvalues.argtypes = [C.c_int, dp, C.c_int, dp, dp]
+        L.oracle_check_schur_form.argtypes = [C.c_int, dp, C.c_int]
+        L.oracle_check_schur_form.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -112,3 +117,47 @@ def orthogonality_u(Q):
 def count_below_subdiagonal(H):
     n = H.shape[1]
     return lib().oracle_count_below_subdiagonal(n, _p(H), H.shape[0])
+
+
+def schur(H, Z):
+    """In-place oracle Schur reduction (double-shift QR) of the upper Hessenberg (ld, n)
+    array H; Z <- Z*U.  Returns (real, imag)."""
+    n = H.shape[1]
+    wr = np.zeros(n); wi = np.zeros(n)
+    rc = lib().oracle_schur(n, _p(H), H.shape[0], _p(Z), Z.shape[0],
+                            wr.ctypes.data_as(C.POINTER(C.c_double)),
+                            wi.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise RuntimeError(f"oracle_schur did not converge (row {rc - 1})")
+    return wr, wi
+
+
+def extract_eigenvalues(S):
+    n = S.shape[1]
+    wr = np.zeros(n); wi = np.zeros(n)
+    lib().oracle_extract_eigenvalues(n, _p(S), S.shape[0],
+                                     wr.ctypes.data_as(C.POINTER(C.c_double)),
+                                     wi.ctypes.data_as(C.POINTER(C.c_double)))
+    return wr, wi
+
+
+def check_schur_form(S):
+    return lib().oracle_check_schur_form(S.shape[1], _p(S), S.shape[0])
+
+
+def match_eigenvalues(ev_a, ev_b):
+    """Greedy nearest-neighbour matching of two eigenvalue multisets, like the reference's
+    known-eigenvalues hook (test/common/hooks.c:1178-1250).  Returns the largest relative
+    difference |a-b| / max(|b|, tiny) over the matching, in units of u = 2^-52."""
+    a = np.asarray(ev_a, dtype=complex).copy()
+    b = list(np.asarray(ev_b, dtype=complex))
+    worst = 0.0
+    scale = max(np.abs(a).max(), 1e-300)
+    order = np.argsort(-np.abs(a))
+    for idx in order:
+        x = a[idx]
+        d = np.abs(np.array(b) - x)
+        k = int(np.argmin(d))
+        worst = max(worst, d[k] / max(abs(x), 1e-3 * scale))
+        b.pop(k)
+    return worst / 2.0 ** -52

@@ -1,0 +1,21 @@
+// Host-side sequential kernels of the Schur path (see schur_host.hip).
+#pragma once
+
+namespace sn { namespace host {
+
+struct AedResult {
+    int deflated;   // converged eigenvalues at the bottom of the window
+    int shifts;     // usable shifts returned in sr/si
+    int failed;     // the window's Schur reduction did not fully converge
+};
+
+void lanv2(double &a, double &b, double &c, double &d,
+    double &rt1r, double &rt1i, double &rt2r, double &rt2i, double &cs, double &sn);
+int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi);
+int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to);
+void extract_eigenvalues(int n, const double *T, int ldt, double *wr, double *wi);
+int extract_shifts(int n, const double *T, int ldt, double *wr, double *wi);
+AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
+    double thres, double *spike, double *sr, double *si);
+
+}} // namespace sn::host

@@ -1,0 +1,581 @@
+// Host-side sequential kernels of the Schur path: the small dense problems that sit on
+// the critical path of the multi-shift QR iteration (rows S4/S6/S8 of SURVEY.md 8a).
+//
+// The reference runs these on a CPU worker through LAPACK (dhseqr, dtrexc, dgehrd,
+// dormhr, dlanv2: schur/cpu_utils.c:2248-2309, :2837-3046, :3377-3416, :3493-3594).
+// There is no LAPACK here; the published algorithms are written out for the sizes this
+// path needs (windows of a few hundred rows).  Everything works on HOST copies of small
+// diagonal windows; the bulk of the flops (off-diagonal updates) stays on the GPU.
+#include "schur_host.h"
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace sn { namespace host {
+
+static inline double sign(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::fabs(a); }
+
+// ---- 2x2 standardisation (LAPACK dlanv2) ---------------------------------------
+void lanv2(double &a, double &b, double &c, double &d,
+    double &rt1r, double &rt1i, double &rt2r, double &rt2i, double &cs, double &sn)
+{
+    const double eps = DBL_EPSILON;
+    if (c == 0.0) { cs = 1.0; sn = 0.0; }
+    else if (b == 0.0) {
+        cs = 0.0; sn = 1.0;
+        std::swap(a, d); b = -c; c = 0.0;
+    }
+    else if (a - d == 0.0 && sign(1.0, b) != sign(1.0, c)) { cs = 1.0; sn = 0.0; }
+    else {
+        double temp = a - d, p = 0.5 * temp;
+        double bcmax = std::max(std::fabs(b), std::fabs(c));
+        double bcmis = std::min(std::fabs(b), std::fabs(c)) * sign(1.0, b) * sign(1.0, c);
+        double scale = std::max(std::fabs(p), bcmax);
+        double z = (p / scale) * p + (bcmax / scale) * bcmis;
+        if (z >= 4.0 * eps) {                       // real eigenvalues
+            z = p + sign(std::sqrt(scale) * std::sqrt(z), p);
+            a = d + z; d = d - (bcmax / z) * bcmis;
+            double tau = std::hypot(c, z);
+            cs = z / tau; sn = c / tau; b = b - c; c = 0.0;
+        } else {                                    // complex or nearly equal real
+            double sigma = b + c, tau = std::hypot(sigma, temp);
+            cs = std::sqrt(0.5 * (1.0 + std::fabs(sigma) / tau));
+            sn = -(p / (tau * cs)) * sign(1.0, sigma);
+            double aa = a * cs + b * sn, bb = -a * sn + b * cs;
+            double cc = c * cs + d * sn, dd = -c * sn + d * cs;
+            a = aa * cs + cc * sn; b = bb * cs + dd * sn;
+            c = -aa * sn + cc * cs; d = -bb * sn + dd * cs;
+            temp = 0.5 * (a + d); a = temp; d = temp;
+            if (c != 0.0) {
+                if (b != 0.0) {
+                    if (sign(1.0, b) == sign(1.0, c)) {
+                        double sab = std::sqrt(std::fabs(b)), sac = std::sqrt(std::fabs(c));
+                        p = sign(sab * sac, c);
+                        tau = 1.0 / std::sqrt(std::fabs(b + c));
+                        a = temp + p; d = temp - p; b = b - c; c = 0.0;
+                        double cs1 = sab * tau, sn1 = sac * tau;
+                        temp = cs * cs1 - sn * sn1; sn = cs * sn1 + sn * cs1; cs = temp;
+                    }
+                } else { b = -c; c = 0.0; temp = cs; cs = -sn; sn = temp; }
+            }
+        }
+    }
+    rt1r = a; rt2r = d;
+    if (c == 0.0) { rt1i = rt2i = 0.0; }
+    else { rt1i = std::sqrt(std::fabs(b)) * std::sqrt(std::fabs(c)); rt2i = -rt1i; }
+}
+
+// Householder vector for x (length n, n <= 4): x <- [beta; v(1:)], returns tau (v(0) = 1).
+static double house(int n, double *x)
+{
+    double xnorm = 0.0;
+    for (int i = 1; i < n; i++) xnorm = std::hypot(xnorm, x[i]);
+    if (xnorm == 0.0) return 0.0;
+    double alpha = x[0];
+    double beta = -sign(std::hypot(alpha, xnorm), alpha);
+    double tau = (beta - alpha) / beta, s = 1.0 / (alpha - beta);
+    for (int i = 1; i < n; i++) x[i] *= s;
+    x[0] = beta;
+    return tau;
+}
+
+#define T_(i, j) T[(size_t)(j) * ldt + (i)]
+#define Z_(i, j) Z[(size_t)(j) * ldz + (i)]
+
+// rotate rows r1, r2 of T over columns [c0, c1): x' = cs x + sn y, y' = cs y - sn x
+static void rot_rows(double *T, int ldt, int r1, int r2, int c0, int c1, double cs, double sn)
+{
+    for (int j = c0; j < c1; j++) {
+        double x = T_(r1, j), y = T_(r2, j);
+        T_(r1, j) = cs * x + sn * y; T_(r2, j) = cs * y - sn * x;
+    }
+}
+static void rot_cols(double *T, int ldt, int c1, int c2, int r0, int r1, double cs, double sn)
+{
+    for (int i = r0; i < r1; i++) {
+        double x = T_(i, c1), y = T_(i, c2);
+        T_(i, c1) = cs * x + sn * y; T_(i, c2) = cs * y - sn * x;
+    }
+}
+
+// ---- double-shift QR on a small Hessenberg matrix (LAPACK dlahqr, full Schur form) ---
+int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi)
+{
+    const double ulp = DBL_EPSILON, safmin = DBL_MIN;
+    const double smlnum = safmin * ((double)n / ulp);
+    const int itmax = 30 * std::max(10, n), kexsh = 10;
+    if (n == 0) return 0;
+    for (int j = 0; j + 2 < n; j++) { T_(j + 2, j) = 0.0; if (j + 3 < n) T_(j + 3, j) = 0.0; }
+
+    int i = n - 1;
+    while (i >= 0) {
+        int l = 0;
+        bool done = false;
+        for (int its = 0; its <= itmax; its++) {
+            int k;
+            for (k = i; k > l; k--) {
+                double sub = std::fabs(T_(k, k - 1));
+                if (sub <= smlnum) break;
+                double tst = std::fabs(T_(k - 1, k - 1)) + std::fabs(T_(k, k));
+                if (tst == 0.0) {
+                    if (k - 2 >= 0) tst += std::fabs(T_(k - 1, k - 2));
+                    if (k + 1 < n) tst += std::fabs(T_(k + 1, k));
+                }
+                if (sub <= ulp * tst) {
+                    double up = std::fabs(T_(k - 1, k));
+                    double ab = std::max(sub, up), ba = std::min(sub, up);
+                    double dd = std::fabs(T_(k - 1, k - 1) - T_(k, k));
+                    double aa = std::max(std::fabs(T_(k, k)), dd), bb = std::min(std::fabs(T_(k, k)), dd);
+                    double s = aa + ab;
+                    if (ba * (ab / s) <= std::max(smlnum, ulp * (bb * (aa / s)))) break;
+                }
+            }
+            l = k;
+            if (l > 0) T_(l, l - 1) = 0.0;
+            if (l >= i - 1) { done = true; break; }
+
+            double h11, h21, h12, h22;
+            if (its > 0 && its % (2 * kexsh) == 0) {
+                double s = std::fabs(T_(l + 1, l)) + std::fabs(T_(l + 2, l + 1));
+                h11 = 0.75 * s + T_(l, l); h12 = -0.4375 * s; h21 = s; h22 = h11;
+            } else if (its > 0 && its % kexsh == 0) {
+                double s = std::fabs(T_(i, i - 1)) + std::fabs(T_(i - 1, i - 2));
+                h11 = 0.75 * s + T_(i, i); h12 = -0.4375 * s; h21 = s; h22 = h11;
+            } else {
+                h11 = T_(i - 1, i - 1); h21 = T_(i, i - 1); h12 = T_(i - 1, i); h22 = T_(i, i);
+            }
+            double rt1r, rt1i, rt2r, rt2i;
+            double s = std::fabs(h11) + std::fabs(h12) + std::fabs(h21) + std::fabs(h22);
+            if (s == 0.0) rt1r = rt1i = rt2r = rt2i = 0.0;
+            else {
+                h11 /= s; h21 /= s; h12 /= s; h22 /= s;
+                double tr = 0.5 * (h11 + h22);
+                double det = (h11 - tr) * (h22 - tr) - h12 * h21;
+                double rtdisc = std::sqrt(std::fabs(det));
+                if (det >= 0.0) { rt1r = tr * s; rt2r = rt1r; rt1i = rtdisc * s; rt2i = -rt1i; }
+                else {
+                    rt1r = tr + rtdisc; rt2r = tr - rtdisc;
+                    if (std::fabs(rt1r - h22) <= std::fabs(rt2r - h22)) { rt1r *= s; rt2r = rt1r; }
+                    else { rt2r *= s; rt1r = rt2r; }
+                    rt1i = rt2i = 0.0;
+                }
+            }
+            double v[3];
+            int m;
+            for (m = i - 2; m >= l; m--) {
+                double h21s = std::fabs(T_(m + 1, m));
+                double ss = std::fabs(T_(m, m) - rt2r) + std::fabs(rt2i) + h21s;
+                h21s = T_(m + 1, m) / ss;
+                v[0] = h21s * T_(m, m + 1) + (T_(m, m) - rt1r) * ((T_(m, m) - rt2r) / ss) - rt1i * (rt2i / ss);
+                v[1] = h21s * (T_(m, m) + T_(m + 1, m + 1) - rt1r - rt2r);
+                v[2] = h21s * T_(m + 2, m + 1);
+                ss = std::fabs(v[0]) + std::fabs(v[1]) + std::fabs(v[2]);
+                v[0] /= ss; v[1] /= ss; v[2] /= ss;
+                if (m == l) break;
+                double nb = std::fabs(T_(m - 1, m - 1)) + std::fabs(T_(m, m)) + std::fabs(T_(m + 1, m + 1));
+                if (std::fabs(T_(m, m - 1)) * (std::fabs(v[1]) + std::fabs(v[2])) <= ulp * std::fabs(v[0]) * nb)
+                    break;
+            }
+            for (int k2 = m; k2 <= i - 1; k2++) {
+                int nr = std::min(3, i - k2 + 1);
+                if (k2 > m) { v[0] = T_(k2, k2 - 1); v[1] = T_(k2 + 1, k2 - 1); if (nr == 3) v[2] = T_(k2 + 2, k2 - 1); }
+                double t1 = house(nr, v);
+                if (k2 > m) { T_(k2, k2 - 1) = v[0]; T_(k2 + 1, k2 - 1) = 0.0; if (k2 < i - 1) T_(k2 + 2, k2 - 1) = 0.0; }
+                else if (m > l) T_(k2, k2 - 1) *= (1.0 - t1);
+                double v2 = v[1], t2 = t1 * v2;
+                if (nr == 3) {
+                    double v3 = v[2], t3 = t1 * v3;
+                    for (int j = k2; j < n; j++) {
+                        double sum = T_(k2, j) + v2 * T_(k2 + 1, j) + v3 * T_(k2 + 2, j);
+                        T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2; T_(k2 + 2, j) -= sum * t3;
+                    }
+                    int je = std::min(k2 + 3, i);
+                    for (int j = 0; j <= je; j++) {
+                        double sum = T_(j, k2) + v2 * T_(j, k2 + 1) + v3 * T_(j, k2 + 2);
+                        T_(j, k2) -= sum * t1; T_(j, k2 + 1) -= sum * t2; T_(j, k2 + 2) -= sum * t3;
+                    }
+                    for (int j = 0; j < n; j++) {
+                        double sum = Z_(j, k2) + v2 * Z_(j, k2 + 1) + v3 * Z_(j, k2 + 2);
+                        Z_(j, k2) -= sum * t1; Z_(j, k2 + 1) -= sum * t2; Z_(j, k2 + 2) -= sum * t3;
+                    }
+                } else {
+                    for (int j = k2; j < n; j++) {
+                        double sum = T_(k2, j) + v2 * T_(k2 + 1, j);
+                        T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2;
+                    }
+                    for (int j = 0; j <= i; j++) {
+                        double sum = T_(j, k2) + v2 * T_(j, k2 + 1);
+                        T_(j, k2) -= sum * t1; T_(j, k2 + 1) -= sum * t2;
+                    }
+                    for (int j = 0; j < n; j++) {
+                        double sum = Z_(j, k2) + v2 * Z_(j, k2 + 1);
+                        Z_(j, k2) -= sum * t1; Z_(j, k2 + 1) -= sum * t2;
+                    }
+                }
+            }
+        }
+        if (!done) return i + 1;
+        if (l == i) { wr[i] = T_(i, i); wi[i] = 0.0; }
+        else {
+            double cs, sn;
+            lanv2(T_(i - 1, i - 1), T_(i - 1, i), T_(i, i - 1), T_(i, i),
+                wr[i - 1], wi[i - 1], wr[i], wi[i], cs, sn);
+            rot_rows(T, ldt, i - 1, i, i + 1, n, cs, sn);
+            rot_cols(T, ldt, i - 1, i, 0, i - 1, cs, sn);
+            rot_cols(Z, ldz, i - 1, i, 0, n, cs, sn);
+        }
+        i = l - 1;
+    }
+    return 0;
+}
+
+// ---- swapping adjacent diagonal blocks of a real Schur form (LAPACK dlaexc) ----------
+// Blocks T11 (n1 x n1) at j1 and T22 (n2 x n2) at j1+n1, n1,n2 in {1,2}.  Returns 0 if
+// swapped, 1 if the swap was rejected as too inaccurate (T, Z untouched).
+static int swap_blocks(int n, double *T, int ldt, double *Z, int ldz, int j1, int n1, int n2)
+{
+    if (n1 == 0 || n2 == 0) return 0;
+    if (j1 + n1 >= n) return 0;
+    const int nd = n1 + n2;
+    if (n1 == 1 && n2 == 1) {
+        double t11 = T_(j1, j1), t22 = T_(j1 + 1, j1 + 1);
+        double f = T_(j1, j1 + 1), g = t22 - t11;
+        double r = std::hypot(f, g), cs, sn;
+        if (r == 0.0) { cs = 1.0; sn = 0.0; } else { cs = f / r; sn = g / r; }
+        rot_rows(T, ldt, j1, j1 + 1, j1 + 2, n, cs, sn);
+        rot_cols(T, ldt, j1, j1 + 1, 0, j1, cs, sn);
+        T_(j1, j1) = t22; T_(j1 + 1, j1 + 1) = t11;
+        rot_cols(Z, ldz, j1, j1 + 1, 0, n, cs, sn);
+        return 0;
+    }
+    // local copy D of the nd x nd diagonal block
+    double D[4][4];
+    double dnorm = 0.0;
+    for (int i = 0; i < nd; i++)
+        for (int j = 0; j < nd; j++) { D[i][j] = T_(j1 + i, j1 + j); dnorm = std::max(dnorm, std::fabs(D[i][j])); }
+    const double eps = DBL_EPSILON, smlnum = DBL_MIN / eps;
+    const double thresh = std::max(10.0 * eps * dnorm, smlnum);
+
+    // Sylvester equation T11 X - X T22 = T12 as a (n1*n2) linear system, complete pivoting
+    const int ns = n1 * n2;
+    double K[4][4] = {{0}}, rhs[4], X[2][2] = {{0}};
+    for (int j = 0; j < n2; j++)
+        for (int i = 0; i < n1; i++) {
+            int row = j * n1 + i;
+            rhs[row] = D[i][n1 + j];
+            for (int p = 0; p < n1; p++) K[row][j * n1 + p] += D[i][p];
+            for (int q = 0; q < n2; q++) K[row][q * n1 + i] -= D[n1 + q][n1 + j];
+        }
+    {
+        int perm[4] = {0, 1, 2, 3};
+        double kmax = 0.0;
+        for (int i = 0; i < ns; i++) for (int j = 0; j < ns; j++) kmax = std::max(kmax, std::fabs(K[i][j]));
+        double smin = std::max(eps * kmax, smlnum);
+        for (int c = 0; c < ns; c++) {
+            int pi = c, pj = c; double pv = 0.0;
+            for (int i = c; i < ns; i++) for (int j = c; j < ns; j++)
+                if (std::fabs(K[i][j]) > pv) { pv = std::fabs(K[i][j]); pi = i; pj = j; }
+            if (pi != c) { for (int j = 0; j < ns; j++) std::swap(K[pi][j], K[c][j]); std::swap(rhs[pi], rhs[c]); }
+            if (pj != c) { for (int i = 0; i < ns; i++) std::swap(K[i][pj], K[i][c]); std::swap(perm[pj], perm[c]); }
+            if (std::fabs(K[c][c]) < smin) K[c][c] = smin;
+            for (int i = c + 1; i < ns; i++) {
+                double f = K[i][c] / K[c][c];
+                for (int j = c; j < ns; j++) K[i][j] -= f * K[c][j];
+                rhs[i] -= f * rhs[c];
+            }
+        }
+        double sol[4];
+        for (int c = ns - 1; c >= 0; c--) {
+            double s = rhs[c];
+            for (int j = c + 1; j < ns; j++) s -= K[c][j] * sol[j];
+            sol[c] = s / K[c][c];
+        }
+        for (int c = 0; c < ns; c++) { int col = perm[c]; X[col % n1][col / n1] = sol[c]; }
+    }
+    // QR of M = [-X; I] (nd x n2): Q^T [T11 T12; 0 T22] Q = [T22' *; 0 T11']
+    double M[4][2], vv[2][4], tau[2];
+    for (int j = 0; j < n2; j++) {
+        for (int i = 0; i < n1; i++) M[i][j] = -X[i][j];
+        for (int i = 0; i < n2; i++) M[n1 + i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int k = 0; k < n2; k++) {
+        double x[4]; int len = nd - k;
+        for (int i = 0; i < len; i++) x[i] = M[k + i][k];
+        tau[k] = house(len, x);
+        vv[k][0] = 1.0; for (int i = 1; i < len; i++) vv[k][i] = x[i];
+        for (int j = k + 1; j < n2; j++) {
+            double s = 0.0;
+            for (int i = 0; i < len; i++) s += vv[k][i] * M[k + i][j];
+            s *= tau[k];
+            for (int i = 0; i < len; i++) M[k + i][j] -= s * vv[k][i];
+        }
+    }
+    // trial on the local copy
+    for (int k = 0; k < n2; k++) {
+        int len = nd - k;
+        for (int j = 0; j < nd; j++) {          // left
+            double s = 0.0;
+            for (int i = 0; i < len; i++) s += vv[k][i] * D[k + i][j];
+            s *= tau[k];
+            for (int i = 0; i < len; i++) D[k + i][j] -= s * vv[k][i];
+        }
+        for (int i = 0; i < nd; i++) {          // right
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += D[i][k + j] * vv[k][j];
+            s *= tau[k];
+            for (int j = 0; j < len; j++) D[i][k + j] -= s * vv[k][j];
+        }
+    }
+    double low = 0.0;
+    for (int i = n2; i < nd; i++) for (int j = 0; j < n2; j++) low = std::max(low, std::fabs(D[i][j]));
+    if (low > thresh) return 1;
+
+    // accept: apply to T and Z
+    for (int k = 0; k < n2; k++) {
+        int len = nd - k, r0 = j1 + k;
+        for (int j = j1; j < n; j++) {
+            double s = 0.0;
+            for (int i = 0; i < len; i++) s += vv[k][i] * T_(r0 + i, j);
+            s *= tau[k];
+            for (int i = 0; i < len; i++) T_(r0 + i, j) -= s * vv[k][i];
+        }
+        for (int i = 0; i < j1 + nd; i++) {
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += T_(i, r0 + j) * vv[k][j];
+            s *= tau[k];
+            for (int j = 0; j < len; j++) T_(i, r0 + j) -= s * vv[k][j];
+        }
+        for (int i = 0; i < n; i++) {
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += Z_(i, r0 + j) * vv[k][j];
+            s *= tau[k];
+            for (int j = 0; j < len; j++) Z_(i, r0 + j) -= s * vv[k][j];
+        }
+    }
+    for (int i = n2; i < nd; i++) for (int j = 0; j < n2; j++) T_(j1 + i, j1 + j) = 0.0;
+    // standardise the new 2x2 blocks
+    auto standardise = [&](int p) {
+        double rt1r, rt1i, rt2r, rt2i, cs, sn;
+        lanv2(T_(p, p), T_(p, p + 1), T_(p + 1, p), T_(p + 1, p + 1), rt1r, rt1i, rt2r, rt2i, cs, sn);
+        rot_rows(T, ldt, p, p + 1, p + 2, n, cs, sn);
+        rot_cols(T, ldt, p, p + 1, 0, p, cs, sn);
+        rot_cols(Z, ldz, p, p + 1, 0, n, cs, sn);
+    };
+    if (n2 == 2) standardise(j1);
+    if (n1 == 2) standardise(j1 + n2);
+    return 0;
+}
+
+// Moves the diagonal block starting at row `from` up to row `to` (to <= from) by adjacent
+// swaps (LAPACK dtrexc, upward direction only; schur/cpu_utils.c:3377-3416).  Returns the
+// row where the block ended up (== to unless a swap was rejected).
+int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
+{
+    int here = from;
+    int nbf = (here + 1 < n && T_(here + 1, here) != 0.0) ? 2 : 1;
+    while (here > to) {
+        int nbabove = (here - 2 >= 0 && T_(here - 1, here - 2) != 0.0) ? 2 : 1;
+        if (here - nbabove < to) break;       // `to` points into the middle of a block
+        int j1 = here - nbabove;
+        if (swap_blocks(n, T, ldt, Z, ldz, j1, nbabove, nbf) != 0) break;
+        here = j1;
+        if (nbf == 2 && T_(here + 1, here) == 0.0) {
+            // the moving 2x2 block split into two 1x1 blocks: move them one at a time
+            int a = move_block_up(n, T, ldt, Z, ldz, here, to);
+            if (a != to) return a;
+            move_block_up(n, T, ldt, Z, ldz, here + 1, to + 1);
+            return a;
+        }
+    }
+    return here;
+}
+
+// ---- shifts (schur/cpu_utils.c:3493-3594) ---------------------------------------------
+void extract_eigenvalues(int n, const double *T, int ldt, double *wr, double *wi)
+{
+    for (int i = 0; i < n; i++) {
+        if (i + 1 < n && T_(i + 1, i) != 0.0) {
+            double a = T_(i, i), b = T_(i, i + 1), c = T_(i + 1, i), d = T_(i + 1, i + 1), cs, sn;
+            lanv2(a, b, c, d, wr[i], wi[i], wr[i + 1], wi[i + 1], cs, sn);
+            i++;
+        } else { wr[i] = T_(i, i); wi[i] = 0.0; }
+    }
+}
+
+int extract_shifts(int n, const double *T, int ldt, double *wr, double *wi)
+{
+    extract_eigenvalues(n, T, ldt, wr, wi);
+    // zero / non-finite shifts go to the end and are dropped (cpu_utils.c:3529-3552)
+    int end = n;
+    for (int i = end - 1; i >= 0; i--) {
+        bool bad = (wr[i] == 0.0 && wi[i] == 0.0) || !std::isfinite(wr[i]) || !std::isfinite(wi[i]);
+        if (bad) { std::swap(wr[i], wr[end - 1]); std::swap(wi[i], wi[end - 1]); end--; }
+    }
+    // ascending |re|+|im| (stable, like the reference's bubble sort :3555-3577)
+    std::vector<int> idx(end);
+    for (int i = 0; i < end; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        return std::fabs(wr[a]) + std::fabs(wi[a]) < std::fabs(wr[b]) + std::fabs(wi[b]); });
+    std::vector<double> r(end), im(end);
+    for (int i = 0; i < end; i++) { r[i] = wr[idx[i]]; im[i] = wi[idx[i]]; }
+    for (int i = 0; i < end; i++) { wr[i] = r[i]; wi[i] = im[i]; }
+    // pair up: (real, real) or (complex, conjugate)  (:3581-3597)
+    for (int i = 0; i + 2 < end; i += 2) {
+        if (wi[i] != -wi[i + 1]) {
+            double sr = wr[i], si = wi[i];
+            wr[i] = wr[i + 1]; wr[i + 1] = wr[i + 2]; wr[i + 2] = sr;
+            wi[i] = wi[i + 1]; wi[i + 1] = wi[i + 2]; wi[i + 2] = si;
+        }
+    }
+    return end;
+}
+
+// ---- Hessenberg reduction of the leading ns x ns part of a window (dgehd2 + dormhr) ----
+// T is the nw x nw window (spike already embedded by the caller in the column to the left,
+// handled through `spike`): rows/cols [0, ns) are reduced, the reflectors are applied to
+// T(0:ns, ns:nw) from the left and accumulated into Z(:, 0:ns) from the right.
+static void hessenberg_small(int nw, int ns, double *T, int ldt, double *Z, int ldz)
+{
+    std::vector<double> v(ns);
+    for (int k = 0; k + 2 < ns; k++) {
+        int len = ns - k - 1;
+        for (int i = 0; i < len; i++) v[i] = T_(k + 1 + i, k);
+        double tau = house(len, v.data());
+        T_(k + 1, k) = v[0];
+        for (int i = 1; i < len; i++) T_(k + 1 + i, k) = 0.0;
+        if (tau == 0.0) continue;
+        v[0] = 1.0;
+        // left: rows k+1..ns-1, columns k+1..nw-1
+        for (int j = k + 1; j < nw; j++) {
+            double s = 0.0;
+            for (int i = 0; i < len; i++) s += v[i] * T_(k + 1 + i, j);
+            s *= tau;
+            for (int i = 0; i < len; i++) T_(k + 1 + i, j) -= s * v[i];
+        }
+        // right: columns k+1..ns-1, rows 0..ns-1
+        for (int i = 0; i < ns; i++) {
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += T_(i, k + 1 + j) * v[j];
+            s *= tau;
+            for (int j = 0; j < len; j++) T_(i, k + 1 + j) -= s * v[j];
+        }
+        for (int i = 0; i < nw; i++) {
+            double s = 0.0;
+            for (int j = 0; j < len; j++) s += Z_(i, k + 1 + j) * v[j];
+            s *= tau;
+            for (int j = 0; j < len; j++) Z_(i, k + 1 + j) -= s * v[j];
+        }
+    }
+}
+
+// ---- aggressive early deflation on a host window (schur/cpu_utils.c:2837-3046) ---------
+// T: nw x nw Hessenberg window; `sub` = the sub-diagonal entry that couples the window to
+// the matrix above it (0 if the window starts the active block).  On return T holds
+// [ Hessenberg (ns x ns) | * ; 0 | Schur (nd x nd) ], Z the accumulated transformation,
+// spike[0:nw] the new first column below the coupling row (sub * Z(0,:), Hessenberg part
+// compressed to its first entry), shifts in sr/si.  Returns nd (deflated eigenvalues).
+AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
+    double thres, double *spike, double *sr, double *si)
+{
+    AedResult res{0, 0, 0};
+    for (int j = 0; j < nw; j++) for (int i = 0; i < nw; i++) Z_(i, j) = (i == j) ? 1.0 : 0.0;
+    std::vector<double> wr(nw), wi(nw);
+    int info = small_schur(nw, T, ldt, Z, ldz, wr.data(), wi.data());
+    int roof = 0;
+    if (info != 0) {
+        // rows [0, info) did not converge: only the trailing part is in Schur form
+        roof = info;
+        res.failed = 1;
+    }
+    const double ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)nw / ulp);
+    int top = roof;           // undeflatable blocks accumulate in [roof, top)
+    int i = nw - 1;
+    while (top <= i) {
+        bool two = (top <= i - 1 && T_(i, i - 1) != 0.0);
+        bool deflatable;
+        if (thres > 0.0) {      // norm-stable criterion (cpu_utils.c:2891-2931)
+            deflatable = std::fabs(sub * Z_(0, i)) < thres &&
+                (!two || std::fabs(sub * Z_(0, i - 1)) < thres);
+        } else {                // LAPACK-style criterion (:2937-2988)
+            double foo = std::fabs(T_(i, i));
+            if (two) foo += std::sqrt(std::fabs(T_(i, i - 1))) * std::sqrt(std::fabs(T_(i - 1, i)));
+            if (foo == 0.0) foo = std::fabs(sub);
+            double sp = std::fabs(sub * Z_(0, i));
+            if (two) sp = std::max(sp, std::fabs(sub * Z_(0, i - 1)));
+            deflatable = sp < std::max(smlnum, ulp * foo);
+        }
+        int bs = two ? 2 : 1;
+        if (deflatable) i -= bs;
+        else {
+            int from = i - bs + 1;
+            int at = move_block_up(nw, T, ldt, Z, ldz, from, top);
+            if (at != top) { top = i + 1; break; }   // swap rejected: nothing below `i` deflates
+            top += bs;
+        }
+    }
+    res.deflated = nw - top;
+    int ns = top;
+    // shifts from the undeflated part; "extract something" if it is too small (:3000-3010)
+    if (ns - roof >= 2) res.shifts = extract_shifts(ns - roof, &T_(roof, roof), ldt, sr, si);
+    else res.shifts = extract_shifts(nw, T, ldt, sr, si);
+    // spike = sub * first row of Z
+    for (int j = 0; j < nw; j++) spike[j] = sub * Z_(0, j);
+    if (res.deflated == 0 && roof == 0) return res;     // caller discards T/Z
+    for (int j = ns; j < nw; j++) spike[j] = 0.0;        // deflated: below the threshold
+    if (ns > 1 && sub != 0.0) {
+        // compress the spike to its first entry with one reflector, then restore Hessenberg
+        std::vector<double> v(ns);
+        for (int j = 0; j < ns; j++) v[j] = spike[j];
+        double tau = house(ns, v.data());
+        spike[0] = v[0];
+        for (int j = 1; j < ns; j++) spike[j] = 0.0;
+        if (tau != 0.0) {
+            v[0] = 1.0;
+            for (int j = 0; j < nw; j++) {           // left on rows [0,ns)
+                double s = 0.0;
+                for (int r = 0; r < ns; r++) s += v[r] * T_(r, j);
+                s *= tau;
+                for (int r = 0; r < ns; r++) T_(r, j) -= s * v[r];
+            }
+            for (int r = 0; r < ns; r++) {           // right on cols [0,ns), rows [0,ns)
+                double s = 0.0;
+                for (int j = 0; j < ns; j++) s += T_(r, j) * v[j];
+                s *= tau;
+                for (int j = 0; j < ns; j++) T_(r, j) -= s * v[j];
+            }
+            for (int r = 0; r < nw; r++) {
+                double s = 0.0;
+                for (int j = 0; j < ns; j++) s += Z_(r, j) * v[j];
+                s *= tau;
+                for (int j = 0; j < ns; j++) Z_(r, j) -= s * v[j];
+            }
+        }
+        hessenberg_small(nw, ns, T, ldt, Z, ldz);
+    }
+    return res;
+}
+
+}} // namespace sn::host
+
+// ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
+extern "C" {
+__attribute__((visibility("default")))
+int sn_internal_small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi)
+{ return sn::host::small_schur(n, T, ldt, Z, ldz, wr, wi); }
+__attribute__((visibility("default")))
+int sn_internal_move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
+{ return sn::host::move_block_up(n, T, ldt, Z, ldz, from, to); }
+__attribute__((visibility("default")))
+int sn_internal_extract_shifts(int n, const double *T, int ldt, double *wr, double *wi)
+{ return sn::host::extract_shifts(n, T, ldt, wr, wi); }
+__attribute__((visibility("default")))
+int sn_internal_aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
+    double thres, double *spike, double *sr, double *si, int *out3)
+{
+    sn::host::AedResult r = sn::host::aed_window(nw, T, ldt, Z, ldz, sub, thres, spike, sr, si);
+    out3[0] = r.deflated; out3[1] = r.shifts; out3[2] = r.failed;
+    return 0;
+}
+}

@@ -1,0 +1,121 @@
+"""CPU suite, part 3: the host-side sequential kernels of the Schur path (small Schur
+reduction, block reordering, shift extraction, AED window) through internal hooks of the
+library -- no GPU involved.  Checked against numpy/LAPACK and the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+import starneig_amd as S
+from helpers import U
+
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def lib():
+    L = S.lib.load()
+    L.sn_internal_small_schur.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, dp]
+    L.sn_internal_move_block_up.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int]
+    L.sn_internal_extract_shifts.argtypes = [C.c_int, dp, C.c_int, dp, dp]
+    L.sn_internal_aed_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double,
+                                         dp, dp, dp, C.POINTER(C.c_int)]
+    return L
+
+
+def hess_input(n, seed=2019):
+    return np.asfortranarray(O.random_hessenberg(n, seed=seed, ld=n))
+
+
+def is_quasi_triangular(T):
+    return O.check_schur_form(np.asfortranarray(T)) == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 75, 200])
+def test_small_schur_matches_oracle_and_numpy(n):
+    H0 = hess_input(n)
+    T = H0.copy(order="F"); Z = np.asfortranarray(np.eye(n))
+    wr = np.zeros(n); wi = np.zeros(n)
+    assert lib().sn_internal_small_schur(n, P(T), n, P(Z), n, P(wr), P(wi)) == 0
+    assert is_quasi_triangular(T)
+    assert np.linalg.norm(Z @ T @ Z.T - H0) <= 200 * U * np.linalg.norm(H0)
+    assert np.linalg.norm(Z @ Z.T - np.eye(n)) <= 200 * U * np.sqrt(n)
+    ev = np.linalg.eigvals(H0)
+    assert O.match_eigenvalues(wr + 1j * wi, ev) < 1e6
+    # same algorithm as the oracle: same eigenvalues to rounding
+    To = H0.copy(order="F"); Zo = np.asfortranarray(np.eye(n))
+    wro, wio = O.schur(To, Zo)
+    assert O.match_eigenvalues(wr + 1j * wi, wro + 1j * wio) < 1e6
+
+
+def test_move_block_up_preserves_similarity_and_order():
+    n = 40
+    H0 = hess_input(n, seed=5)
+    T = H0.copy(order="F"); Z = np.asfortranarray(np.eye(n))
+    wr = np.zeros(n); wi = np.zeros(n)
+    lib().sn_internal_small_schur(n, P(T), n, P(Z), n, P(wr), P(wi))
+    ev_before = wr + 1j * wi
+    # move the last block to the top
+    frm = n - 2 if T[n - 1, n - 2] != 0 else n - 1
+    moving = ev_before[frm]
+    at = lib().sn_internal_move_block_up(n, P(T), n, P(Z), n, frm, 0)
+    assert at == 0
+    assert is_quasi_triangular(T)
+    assert np.linalg.norm(Z @ T @ Z.T - H0) <= 500 * U * np.linalg.norm(H0)
+    wr2, wi2 = O.extract_eigenvalues(np.asfortranarray(T))
+    ev_after = wr2 + 1j * wi2
+    assert abs(ev_after[0].real - moving.real) <= 1e-8 * max(1, abs(moving))
+    assert O.match_eigenvalues(ev_after, ev_before) < 1e8
+
+
+def test_extract_shifts_order_and_pairing():
+    """schur/cpu_utils.c:3522-3594: ascending |re|+|im|, zero/inf dropped, conjugates adjacent."""
+    blocks = [np.array([[3.0]]), np.array([[1.0, 2.0], [-2.0, 1.0]]), np.array([[0.0]]),
+              np.array([[-0.5]]), np.array([[4.0, 1.0], [-1.0, 4.0]]), np.array([[2.0]])]
+    n = sum(b.shape[0] for b in blocks)
+    T = np.zeros((n, n), order="F"); k = 0
+    for b in blocks:
+        T[k:k + b.shape[0], k:k + b.shape[0]] = b; k += b.shape[0]
+    wr = np.zeros(n); wi = np.zeros(n)
+    cnt = lib().sn_internal_extract_shifts(n, P(T), n, P(wr), P(wi))
+    assert cnt == n - 1                                   # the zero eigenvalue is dropped
+    for i in range(0, cnt - 1, 2):
+        assert wi[i] == -wi[i + 1]
+    mags = np.abs(wr[:cnt]) + np.abs(wi[:cnt])
+    assert mags[0] == 0.5
+    assert np.allclose(sorted(mags), [0.5, 2.0, 3.0, 3.0, 3.0, 5.0, 5.0], rtol=1e-14)
+
+
+@pytest.mark.parametrize("nw,sub_scale", [(30, 1e-3), (60, 1e-1), (100, 1e-8)])
+def test_aed_window_invariants(nw, sub_scale):
+    """After AED: T = [Hessenberg | *; 0 | Schur], Z orthogonal, Z T Z^T + spike consistent
+    with the original window, deflated spike entries were below the threshold."""
+    W0 = hess_input(nw, seed=11)
+    sub = sub_scale
+    thres = U * np.linalg.norm(W0) * 50           # generous threshold so something deflates
+    T = W0.copy(order="F"); Z = np.zeros((nw, nw), order="F")
+    spike = np.zeros(nw); sr = np.zeros(nw); si = np.zeros(nw)
+    out = (C.c_int * 3)()
+    lib().sn_internal_aed_window(nw, P(T), nw, P(Z), nw, sub, thres, P(spike), P(sr), P(si), out)
+    nd, nshift, failed = out[0], out[1], out[2]
+    assert failed == 0
+    assert np.linalg.norm(Z @ Z.T - np.eye(nw)) <= 500 * U * np.sqrt(nw)
+    if nd == 0:
+        return
+    ns = nw - nd
+    # similarity on the window
+    assert np.linalg.norm(Z @ T @ Z.T - W0) <= 1000 * U * np.linalg.norm(W0)
+    # structure: leading ns x ns Hessenberg, trailing nd x nd quasi-triangular, zero coupling
+    assert np.all(np.tril(T[:ns, :ns], -2) == 0.0)
+    assert np.all(T[ns:, :ns] == 0.0)
+    assert is_quasi_triangular(T[ns:, ns:])
+    # the spike: sub * e1^T Z, compressed to one entry on the Hessenberg part, zero on the rest
+    full = sub * Z[0, :]
+    assert np.all(spike[1:] == 0.0)
+    assert abs(abs(spike[0]) - np.linalg.norm(full[:ns])) <= 100 * U * abs(sub)
+    assert np.all(np.abs(full[ns:]) < thres)
+    assert nshift <= nw
