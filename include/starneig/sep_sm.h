@@ -1,6 +1,6 @@
 /* Standard eigenvalue problem, shared memory (one node).  Replaces: reference
- * src/include/starneig/sep_sm.h:89-92 (Hessenberg), :380-384 (expert variant); the Schur entry points
- * (:126-130, :424-429) are added with the Schur path.  All arrays are HOST pointers,
+ * src/include/starneig/sep_sm.h:89-92 (Hessenberg), :126-130 (Schur),
+ * :380-384 and :424-429 (expert variants).  All arrays are HOST pointers,
  * column-major, results are written in place, exactly as in the reference;
  * the library moves them to HBM, runs the HIP path and copies back. */
 #ifndef STARNEIG_AMD_SEP_SM_H
@@ -23,6 +23,28 @@ starneig_error_t starneig_SEP_SM_Hessenberg(
 starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     struct starneig_hessenberg_conf *conf, int n, int begin, int end,
     double A[], int ldA, double Q[], int ldQ);
+
+/* H (upper Hessenberg) <- S (real Schur form, 2x2 blocks standardised),
+ * Q <- Q*U; real/imag receive the eigenvalues in diagonal order (may be NULL).
+ * Errors: n<1 -> -1, H NULL -> -2, ldH<n -> -3, Q NULL -> -4, ldQ<n -> -5
+ * (schur/interface.c:228-232); STARNEIG_DID_NOT_CONVERGE. */
+starneig_error_t starneig_SEP_SM_Schur(
+    int n, double H[], int ldH, double Q[], int ldQ,
+    double real[], double imag[]);
+
+/* Errors: n<1 -> -2, H NULL -> -3, ldH<n -> -4, Q NULL -> -5, ldQ<n -> -6
+ * (schur/interface.c:198-202). */
+starneig_error_t starneig_SEP_SM_Schur_expert(
+    struct starneig_schur_conf *conf, int n, double H[], int ldH,
+    double Q[], int ldQ, double real[], double imag[]);
+
+/* Hessenberg followed by Schur (the reordering leg of common/combined.c:46-98
+ * is outside this path: predicate must be NULL). */
+starneig_error_t starneig_SEP_SM_Reduce(
+    int n, double A[], int ldA, double Q[], int ldQ,
+    double real[], double imag[],
+    int (*predicate)(double real, double imag, void *arg), void *arg,
+    int selected[], int *num_selected);
 
 #ifdef __cplusplus
 }

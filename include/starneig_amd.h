@@ -26,6 +26,18 @@ starneig_error_t starneig_amd_hessenberg_device(
     int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, void *stream, double *stats);
 
+/* Replaces starneig_schur_insert_tasks (schur/core.c:2342-2514) + the window and update
+ * codelets (schur/cpu.c, cpu_utils.c, common/cpu.c:54-162) on a device-resident upper
+ * Hessenberg matrix: dH <- real Schur form, dQ <- dQ*U (dQ may be NULL).  real/imag are
+ * HOST arrays of length n (both NULL = not extracted).  conf may be NULL (defaults).
+ * stats (may be NULL) is double[8]: [0] total ms, [1] QR sweeps, [2] AED calls,
+ * [3] small host solves, [4] chase launches, [5] executed GEMM flops.
+ * Returns STARNEIG_DID_NOT_CONVERGE like schur/core.c:2324-2326. */
+struct starneig_schur_conf;
+starneig_error_t starneig_amd_schur_device(
+    int n, double *dH, int ldH, double *dQ, int ldQ, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats);
+
 /* fp64 MFMA GEMM, BLAS dgemm semantics on device pointers (the kernel behind
  * rows H4-H8 and S3; replaces cblas_dgemm/cublasDgemm call sites). */
 starneig_error_t starneig_amd_dgemm_device(

@@ -6,11 +6,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include <starneig/starneig.h>
 #include <starneig_amd.h>
 
 namespace sn {
 void hessenberg_release_workspace();
+void schur_release_workspace();
 void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
     double ident, double *acc);
 void count_below(hipStream_t s, int n, double const *H, int ldh, double *acc);
@@ -85,6 +87,7 @@ SN_API void starneig_node_finalize(void)
     if (!g_node.initialized) return;
     SN_HIP_CHECK(hipDeviceSynchronize());
     sn::hessenberg_release_workspace();
+    sn::schur_release_workspace();
     g_node.initialized = false;
 }
 
@@ -104,7 +107,11 @@ SN_API void starneig_schur_init_conf(struct starneig_schur_conf *conf)
 
 SN_API int starneig_amd_default_panel_width(int n) { return default_panel_width(n); }
 
-SN_API void starneig_amd_release_workspace(void) { sn::hessenberg_release_workspace(); }
+SN_API void starneig_amd_release_workspace(void)
+{
+    sn::hessenberg_release_workspace();
+    sn::schur_release_workspace();
+}
 
 // ---- host-array interface (in place, like the reference) ----------------------
 
@@ -173,7 +180,130 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg(
     return starneig_SEP_SM_Hessenberg_expert(NULL, n, 0, n, A, ldA, Q, ldQ);
 }
 
+// schur/process_args.c:278-437: range checks of the expert configuration
+static int schur_params_from_conf(struct starneig_schur_conf const *conf, sn::SchurParams &p)
+{
+    if (conf == NULL) return STARNEIG_SUCCESS;
+    auto bad_int = [](int v) { return v != -1 && v < 1; };
+    if (bad_int(conf->iteration_limit) || bad_int(conf->small_limit) ||
+        bad_int(conf->aed_window_size) || bad_int(conf->shift_count) ||
+        (conf->tile_size != -1 && conf->tile_size < 8))
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_nibble != -1 && (conf->aed_nibble < 1 || conf->aed_nibble > 99))
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_window_size > 0 && conf->shift_count > 0 &&
+        conf->shift_count > conf->aed_window_size)
+        return STARNEIG_INVALID_ARGUMENTS;          // process_args.c:340-352
+    double lt = conf->left_threshold;
+    if (!(lt == -1.0 || lt == -2.0 || lt == -3.0 || lt > 0.0))
+        return STARNEIG_INVALID_CONFIGURATION;      // schur/core.c:2360-2384
+    p.iteration_limit = conf->iteration_limit;
+    p.small_limit = conf->small_limit;
+    p.aed_window_size = conf->aed_window_size;
+    p.aed_nibble = conf->aed_nibble;
+    p.shift_count = conf->shift_count;
+    p.threshold = lt;
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
+    struct starneig_schur_conf *conf, int n, double H[], int ldH,
+    double Q[], int ldQ, double real[], double imag[])
+{
+    if (n < 1)      return -2;           // schur/interface.c:198-202
+    if (H == NULL)  return -3;
+    if (ldH < n)    return -4;
+    if (Q == NULL)  return -5;
+    if (ldQ < n)    return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::SchurParams prm;
+    int rc = schur_params_from_conf(conf, prm);
+    if (rc != STARNEIG_SUCCESS) return rc;
+
+    int const ld = (int)sn::roundup(n, 16);
+    size_t const bytes = (size_t)ld * n * sizeof(double);
+    double *dH = nullptr, *dQ = nullptr;
+    SN_HIP_CHECK(hipMalloc((void **)&dH, bytes));
+    SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+    SN_HIP_CHECK(hipMemset(dH, 0, bytes));
+    SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
+    SN_HIP_CHECK(hipMemcpy2D(dH, (size_t)ld * 8, H, (size_t)ldH * 8, (size_t)n * 8, n,
+        hipMemcpyHostToDevice));
+    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n,
+        hipMemcpyHostToDevice));
+    std::vector<double> wr, wi;
+    double *pr = real, *pi = imag;
+    if (real == NULL || imag == NULL) { pr = pi = nullptr; }    // schur/core.c:2501
+    rc = sn::schur_device(nullptr, n, dH, ld, dQ, ld, pr, pi, prm, nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+    SN_HIP_CHECK(hipMemcpy2D(H, (size_t)ldH * 8, dH, (size_t)ld * 8, (size_t)n * 8, n,
+        hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n,
+        hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipFree(dH));
+    SN_HIP_CHECK(hipFree(dQ));
+    return rc;
+}
+
+SN_API starneig_error_t starneig_SEP_SM_Schur(
+    int n, double H[], int ldH, double Q[], int ldQ, double real[], double imag[])
+{
+    if (n < 1)      return -1;           // schur/interface.c:228-232
+    if (H == NULL)  return -2;
+    if (ldH < n)    return -3;
+    if (Q == NULL)  return -4;
+    if (ldQ < n)    return -5;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    return starneig_SEP_SM_Schur_expert(NULL, n, H, ldH, Q, ldQ, real, imag);
+}
+
+// common/combined.c:46-98 without the reordering leg (predicate must be NULL)
+SN_API starneig_error_t starneig_SEP_SM_Reduce(
+    int n, double A[], int ldA, double Q[], int ldQ, double real[], double imag[],
+    int (*predicate)(double real, double imag, void *arg), void *arg,
+    int selected[], int *num_selected)
+{
+    if (n < 1)      return -1;
+    if (A == NULL)  return -2;
+    if (ldA < n)    return -3;
+    if (Q == NULL)  return -4;
+    if (ldQ < n)    return -5;
+    if (real == NULL) return -6;
+    if (imag == NULL) return -7;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    if (predicate != NULL) return STARNEIG_GENERIC_ERROR;   // reordering is outside this path
+    (void)arg; (void)selected;
+    if (num_selected) *num_selected = 0;
+    starneig_error_t rc = starneig_SEP_SM_Hessenberg(n, A, ldA, Q, ldQ);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    return starneig_SEP_SM_Schur(n, A, ldA, Q, ldQ, real, imag);
+}
+
 // ---- device-pointer extension -------------------------------------------------
+
+SN_API starneig_error_t starneig_amd_schur_device(
+    int n, double *dH, int ldH, double *dQ, int ldQ, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (dH == NULL)            return -2;
+    if (ldH < n)               return -3;
+    if (dQ != NULL && ldQ < n) return -5;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::SchurParams prm;
+    int rc = schur_params_from_conf(conf, prm);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    sn::SchurStats st;
+    hipStream_t s = (hipStream_t)stream;
+    if (real == NULL || imag == NULL) real = imag = nullptr;
+    rc = sn::schur_device(s, n, dH, ldH, dQ, ldQ, real, imag, prm, &st);
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    if (stats) {
+        stats[0] = st.total_ms; stats[1] = st.sweeps; stats[2] = st.aeds;
+        stats[3] = st.small_solves; stats[4] = st.chase_launches; stats[5] = st.gemm_flops;
+    }
+    return rc;
+}
 
 SN_API starneig_error_t starneig_amd_hessenberg_device(
     int n, int begin, int end, int panel_width,

@@ -28,6 +28,11 @@ void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
     double alpha, double const *A, int lda, double const *B, int ldb,
     double beta, double *C, int ldc);
 
+void dgemm_left_inplace(hipStream_t s, int w, int ncols, double const *U, int ldu,
+    double *X, int ldx);
+void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int ldu,
+    double *X, int ldx);
+
 // ---- small helpers (util.hip) -----------------------------------------------
 void copy_matrix(hipStream_t s, int m, int n, double const *A, int lda,
     double *B, int ldb);
@@ -56,5 +61,25 @@ struct HessenbergTimings {
 // caller: all work is enqueued on ctx streams and joined back into `s`.
 int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *timings);
+
+// ---- Schur (schur.hip) -----------------------------------------------------------
+struct SchurParams {            // resolved from starneig_schur_conf (negative = default)
+    int iteration_limit = -1;
+    int small_limit = -1;
+    int aed_window_size = -1;
+    int aed_nibble = -1;
+    int shift_count = -1;
+    double threshold = -1.0;    // -1/-2: norm-stable (u*||H||_F), -3: LAPACK criterion, >0: absolute
+};
+struct SchurStats {
+    int sweeps = 0, aeds = 0, small_solves = 0, chase_launches = 0;
+    double gemm_flops = 0.0;
+    float total_ms = 0.f;
+};
+// Reduces the device-resident upper Hessenberg matrix dH to real Schur form, dQ <- dQ*U.
+// real/imag are HOST arrays (may be NULL).  Returns a starneig_error_t value.
+int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
+    double *real, double *imag, SchurParams const &params, SchurStats *stats);
+void schur_release_workspace();
 
 } // namespace sn

@@ -200,6 +200,27 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
         launch<64, 64, 16, TA, TB>(s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
+// In-place window updates of the Schur path (row S3): X(w x ncols) <- U^T X and
+// X(nrows x w) <- X U with a small orthogonal U (w <= 128).  One workgroup owns ALL w rows
+// (resp. columns) of its output tile and reads its whole operand panel before the
+// epilogue writes, so the update is safe in place (no scratch copy, unlike the reference's
+// two scratch buffers per task, common/tasks.c:459-462).
+void dgemm_left_inplace(hipStream_t s, int w, int ncols, double const *U, int ldu,
+    double *X, int ldx)
+{
+    if (w <= 0 || ncols <= 0) return;
+    if (w > 128) { fprintf(stderr, "[starneig-amd] dgemm_left_inplace: w > 128\n"); abort(); }
+    launch<128, 128, 16, true, false>(s, w, ncols, w, 1.0, U, ldu, X, ldx, 0.0, X, ldx);
+}
+
+void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int ldu,
+    double *X, int ldx)
+{
+    if (w <= 0 || nrows <= 0) return;
+    if (w > 128) { fprintf(stderr, "[starneig-amd] dgemm_right_inplace: w > 128\n"); abort(); }
+    launch<128, 128, 16, false, false>(s, nrows, w, w, 1.0, X, ldx, U, ldu, 0.0, X, ldx);
+}
+
 void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
     double alpha, double const *A, int lda, double const *B, int ldb,
     double beta, double *C, int ldc)

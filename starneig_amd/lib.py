@@ -61,6 +61,13 @@ SIGNATURES = {
     "starneig_SEP_SM_Hessenberg": (C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int]),
     "starneig_SEP_SM_Hessenberg_expert": (
         C.c_int, [C.POINTER(HessenbergConf), C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "starneig_SEP_SM_Schur": (C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "starneig_SEP_SM_Schur_expert": (
+        C.c_int, [C.POINTER(SchurConf), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "starneig_SEP_SM_Reduce": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "starneig_amd_schur_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
         C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
     "starneig_amd_dgemm_device": (
@@ -137,6 +144,34 @@ def SEP_SM_Hessenberg_expert(conf, n, begin, end, A, ldA, Q, ldQ):
         cp, n, begin, end, _host_ptr(A), ldA, _host_ptr(Q), ldQ)
 
 
+def schur_init_conf():
+    conf = SchurConf()
+    load().starneig_schur_init_conf(C.byref(conf))
+    return conf
+
+
+def SEP_SM_Schur(n, H, ldH, Q, ldQ, real, imag):
+    """reference sep_sm.h:126-130; real/imag: float64 arrays of length n or None."""
+    return load().starneig_SEP_SM_Schur(
+        n, _host_ptr(H), ldH, _host_ptr(Q), ldQ,
+        None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data)
+
+
+def SEP_SM_Schur_expert(conf, n, H, ldH, Q, ldQ, real, imag):
+    """reference sep_sm.h:424-429."""
+    cp = C.byref(conf) if conf is not None else None
+    return load().starneig_SEP_SM_Schur_expert(
+        cp, n, _host_ptr(H), ldH, _host_ptr(Q), ldQ,
+        None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data)
+
+
+def SEP_SM_Reduce(n, A, ldA, Q, ldQ, real, imag):
+    """reference sep_sm.h (Reduce) without predicate/selection."""
+    return load().starneig_SEP_SM_Reduce(
+        n, _host_ptr(A), ldA, _host_ptr(Q), ldQ, real.ctypes.data, imag.ctypes.data,
+        None, None, None, None)
+
+
 # ---- device-pointer extension (torch tensors only carry the memory) ---------------
 
 def _dev_ptr(t):
@@ -171,6 +206,21 @@ def hessenberg_device(tA, tQ, n=None, begin=0, end=None, panel_width=-1, stats=F
                     "gemv_sampled_ms": st[3], "gemv_sampled_bytes": st[4],
                     "gemv_launches": int(st[5]), "gemv_sampled_launches": int(st[6])}
     return rc
+
+
+def schur_device(tH, tQ, n=None, conf=None, eigenvalues=True):
+    """Returns (rc, real, imag, stats)."""
+    n = tH.shape[0] if n is None else n
+    real = np.zeros(n) if eigenvalues else None
+    imag = np.zeros(n) if eigenvalues else None
+    st = (C.c_double * 8)()
+    rc = load().starneig_amd_schur_device(
+        n, _dev_ptr(tH), tH.shape[1], _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0,
+        None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data,
+        C.byref(conf) if conf is not None else None, _stream_ptr(), st)
+    stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
+             "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5]}
+    return rc, real, imag, stats
 
 
 def dgemm_device(transA, transB, m, n, k, alpha, tA, ldA, tB, ldB, beta, tC, ldC):

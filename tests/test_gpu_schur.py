@@ -1,0 +1,131 @@
+"""GPU parity tests of the Schur leg: the HIP multi-shift QR path, called through the C-ABI,
+against the CPU oracle (double-shift QR restatement) on the same seeded inputs, plus the
+reference's own acceptance checks (test/common/hooks.c:535-714 Schur form, :891-991 eigenvalue
+self-consistency, checks.c:180-208 residuals).  Schur forms are not unique, so parity is on
+invariants: eigenvalue multisets, structure, residual, orthogonality.
+
+Tolerances (units of u = 2^-52, relative to max(|lambda|, 1e-3 max|lambda|)):
+  eigenvalues vs oracle: 1e4 u for the dense LCG matrices (the reference's warn threshold),
+  1e6 u for random Hessenberg input (its fail threshold; those spectra are ill-conditioned)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import U, WARN_U, to_device, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def hessenberg_of_lcg(n):
+    """Schur input = oracle Hessenberg form of the LCG matrix (test/schur 'lapack' initializer)."""
+    A0 = O.random_fullpos(n)
+    H = A0.copy(order="F"); Q = O.identity(n)
+    O.hessenberg(H, Q)
+    return A0, H, Q
+
+
+def check_result(S, H0, Hs, Q0, Qs, real, imag, eig_tol_u):
+    n = H0.shape[1]
+    assert O.check_schur_form(Hs) == 0
+    # Qs S Qs^T == Q0 H0 Q0^T
+    X = Q0[:n] @ H0[:n] @ Q0[:n].T
+    R = Qs[:n] @ Hs[:n] @ Qs[:n].T - X
+    assert np.linalg.norm(R) / np.linalg.norm(X) < WARN_U * U
+    assert O.orthogonality_u(Qs) < WARN_U
+    # returned eigenvalues == eigenvalues of the diagonal blocks (reference 'eigenvalues' hook)
+    wr, wi = O.extract_eigenvalues(Hs)
+    assert O.match_eigenvalues(real + 1j * imag, wr + 1j * wi) < 1e3
+    # conjugate pairs adjacent, positive imaginary part first (sep_sm.h:100-120)
+    i = 0
+    while i < n:
+        if imag[i] != 0.0:
+            assert imag[i] > 0 and imag[i + 1] == -imag[i] and real[i + 1] == real[i]
+            i += 2
+        else:
+            i += 1
+    # eigenvalue multiset against the oracle
+    Ho = H0.copy(order="F"); Zo = O.identity(n, ld=H0.shape[0])
+    wro, wio = O.schur(Ho, Zo)
+    assert O.match_eigenvalues(real + 1j * imag, wro + 1j * wio) < eig_tol_u
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 50, 128, 129, 200, 400, 1000])
+def test_schur_of_lcg_hessenberg_matches_oracle(node, n):
+    A0, H0, Q0 = hessenberg_of_lcg(n)
+    H = H0.copy(order="F"); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
+    check_result(node, H0, H, Q0, Q, real, imag, 1e4)
+    # the whole chain reproduces the original dense matrix
+    assert O.residual_u(Q, H, A0) < WARN_U
+
+
+@pytest.mark.parametrize("n", [150, 300, 700])
+def test_schur_of_random_hessenberg(node, n):
+    """the test driver's `schur --init random`: random Hessenberg, 2*prand-1 (init.c:159-175)"""
+    H0 = O.random_hessenberg(n)
+    H = H0.copy(order="F"); Q0 = O.identity(n); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
+    check_result(node, H0, H, Q0, Q, real, imag, 1e6)
+
+
+@pytest.mark.parametrize("aed,shifts,small", [(50, 20, 100), (100, 60, 128), (200, 120, 150), (24, 8, 100)])
+def test_expert_configurations(node, aed, shifts, small):
+    """reference CTest sweep over AED sizes / shift counts (test/CMakeLists.txt:419-444)"""
+    n = 500
+    A0, H0, Q0 = hessenberg_of_lcg(n)
+    conf = node.schur_init_conf()
+    conf.aed_window_size = aed; conf.shift_count = shifts; conf.small_limit = small
+    H = H0.copy(order="F"); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur_expert(conf, n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
+    check_result(node, H0, H, Q0, Q, real, imag, 1e4)
+
+
+def test_lapack_threshold_and_null_eigenvalue_arrays(node):
+    n = 300
+    A0, H0, Q0 = hessenberg_of_lcg(n)
+    conf = node.schur_init_conf()
+    conf.left_threshold = -3.0          # STARNEIG_SCHUR_LAPACK_THRESHOLD
+    H = H0.copy(order="F"); Q = Q0.copy(order="F")
+    assert node.SEP_SM_Schur_expert(conf, n, H, H.shape[0], Q, Q.shape[0], None, None) == 0
+    assert O.check_schur_form(H) == 0
+    assert O.residual_u(Q, H, A0) < WARN_U
+    conf.left_threshold = -7.0
+    assert node.SEP_SM_Schur_expert(conf, n, H, H.shape[0], Q, Q.shape[0], None, None) == node.INVALID_CONFIGURATION
+    conf = node.schur_init_conf(); conf.aed_window_size = 10; conf.shift_count = 20
+    assert node.SEP_SM_Schur_expert(conf, n, H, H.shape[0], Q, Q.shape[0], None, None) == node.INVALID_ARGUMENTS
+
+
+def test_already_triangular_and_block_diagonal_inputs(node):
+    n = 260
+    rng = np.random.RandomState(3)
+    T0 = np.asfortranarray(np.triu(rng.uniform(-1, 1, (n, n))))
+    T = T0.copy(order="F"); Q = np.asfortranarray(np.eye(n))
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, T, n, Q, n, real, imag) == 0
+    assert np.array_equal(T, T0) and np.array_equal(Q, np.eye(n))
+    assert np.array_equal(real, np.diag(T0)) and not imag.any()
+    # two decoupled Hessenberg blocks (exact zero on the sub-diagonal)
+    H0 = O.random_hessenberg(n, ld=n); H0[130, 129] = 0.0
+    H = H0.copy(order="F"); Q = np.asfortranarray(np.eye(n))
+    assert node.SEP_SM_Schur(n, H, n, Q, n, real, imag) == 0
+    check_result(node, H0, H, np.asfortranarray(np.eye(n)), Q, real, imag, 1e6)
+
+
+def test_full_chain_reduce_config1(node):
+    """BASELINE config 1: Hessenberg + Schur of the 2000 x 2000 matrix, via starneig_SEP_SM_Reduce
+    (common/combined.c:46-98) -- checks of examples/validate.c:63-65,99-101 (1000 u limit)."""
+    n = 2000
+    A0 = O.random_fullpos(n)
+    A = A0.copy(order="F"); Q = O.identity(n)
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Reduce(n, A, A.shape[0], Q, Q.shape[0], real, imag) == 0
+    assert O.check_schur_form(A) == 0
+    tA, tQ, tA0 = to_device(A), to_device(Q), to_device(A0)
+    rc, chk = node.check_device(tQ, tA, tA0, n=n)
+    assert rc == 0 and chk["residual_u"] < 1000 and chk["orthogonality_u"] < 1000
+    # trace and the dominant (Perron) eigenvalue of the positive matrix are preserved
+    assert abs(real.sum() - np.trace(A0[:n])) <= 1e-10 * abs(np.trace(A0[:n]))
+    assert abs(real.max() - np.abs(np.linalg.eigvals(A0[:n])).max()) <= 1e-10 * n
