@@ -56,18 +56,27 @@ __device__ __forceinline__ void shift_vector(double const *W, double sr1, double
     v[2] = h31s * (h11 + h33 - sr1 - sr2) + h21s * h32;
 }
 
-// Householder reflector I - tau [1;v1;v2][1;v1;v2]^T mapping x to beta e1 (len 2 or 3)
+// Householder reflector I - tau [1;v1;v2][1;v1;v2]^T mapping x to beta e1 (len 2 or 3).
+// x is scaled by its largest entry first: bulges that pass an (almost) converged part of
+// the matrix shrink to 1e-150 and below, where x^2 would lose its bits to underflow
+// (LAPACK dlarfg handles the same situation with its safmin rescaling loop).
 __device__ __forceinline__ void small_reflector(int len, double const *x,
     double &beta, double &v1, double &v2, double &tau)
 {
-    double x1 = x[1], x2 = len == 3 ? x[2] : 0.0;
-    double xn2 = x1 * x1 + x2 * x2;
-    if (xn2 == 0.0) { beta = x[0]; v1 = v2 = 0.0; tau = 0.0; return; }
-    double alpha = x[0];
-    beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-    tau = (beta - alpha) / beta;
-    double sc = 1.0 / (alpha - beta);
-    v1 = x1 * sc; v2 = x2 * sc;
+    double x0 = x[0], x1 = x[1], x2 = len == 3 ? x[2] : 0.0;
+    double const m = fmax(fabs(x0), fmax(fabs(x1), fabs(x2)));
+    // (entries below 1e-290 cannot be scaled safely and are dropped: they are far below any
+    // deflation threshold)
+    if ((x1 == 0.0 && x2 == 0.0) || !(m > 1e-290) || !(fmax(fabs(x1), fabs(x2)) > 1e-290)) {
+        beta = x0; v1 = v2 = 0.0; tau = 0.0; return;
+    }
+    double const im = 1.0 / m;
+    double a = x0 * im, b1 = x1 * im, b2 = x2 * im;
+    double bs = -copysign(sqrt(a * a + b1 * b1 + b2 * b2), a);
+    tau = (bs - a) / bs;
+    double sc = 1.0 / (a - bs);
+    v1 = b1 * sc; v2 = b2 * sc;
+    beta = bs * m;
 }
 
 // One workgroup chases one chain of bulges through one diagonal window held in LDS
@@ -372,9 +381,47 @@ struct Driver {
             if (ntasks == 0) continue;
             SN_HIP_CHECK(hipMemcpyAsync(dtasks, htasks, (size_t)ntasks * sizeof(ChaseTask),
                 hipMemcpyHostToDevice, s));
+            std::vector<double> dbg_win;
+            if (getenv("SN_SCHUR_DEBUG")) {
+                SN_HIP_CHECK(hipStreamSynchronize(s));
+                dbg_win.resize((size_t)ntasks * WS_MAX * WS_MAX);
+                for (int k = 0; k < ntasks; k++)
+                    SN_HIP_CHECK(hipMemcpy2D(dbg_win.data() + (size_t)k * WS_MAX * WS_MAX, WS_MAX * 8,
+                        H + (size_t)htasks[k].lo * ldH + htasks[k].lo, (size_t)ldH * 8,
+                        (size_t)htasks[k].n * 8, htasks[k].n, hipMemcpyDeviceToHost));
+            }
             hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(256), CHASE_LDS_BYTES, s,
                 dtasks, H, ldH, ws.dU, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
+            if (getenv("SN_SCHUR_DEBUG")) {
+                SN_HIP_CHECK(hipStreamSynchronize(s));
+                std::vector<double> hu((size_t)WS_MAX * WS_MAX);
+                for (int k = 0; k < ntasks; k++) {
+                    SN_HIP_CHECK(hipMemcpy(hu.data(), ws.dU + (size_t)k * WS_MAX * WS_MAX,
+                        hu.size() * 8, hipMemcpyDeviceToHost));
+                    int w = htasks[k].n; double worst = 0.0;
+                    for (int a = 0; a < w; a++) for (int b = 0; b < w; b++) {
+                        double dot = 0.0;
+                        for (int r = 0; r < w; r++) dot += hu[(size_t)a * WS_MAX + r] * hu[(size_t)b * WS_MAX + r];
+                        worst = std::max(worst, std::fabs(dot - (a == b ? 1.0 : 0.0)));
+                    }
+                    if (worst > 1e-12) {
+                        FILE *f = fopen("gpurun_out/bad_window.bin", "wb");
+                        if (f) {
+                            int hdr[4] = {htasks[k].n, htasks[k].nb, htasks[k].flags, htasks[k].right};
+                            fwrite(hdr, sizeof(int), 4, f);
+                            fwrite(dbg_win.data() + (size_t)k * WS_MAX * WS_MAX, 8, (size_t)WS_MAX * WS_MAX, f);
+                            fwrite(sr + htasks[k].shift_off, 8, 2 * htasks[k].nb, f);
+                            fwrite(si + htasks[k].shift_off, 8, 2 * htasks[k].nb, f);
+                            fwrite(hu.data(), 8, hu.size(), f);
+                            fclose(f);
+                        }
+                    }
+                    if (worst > 1e-12 || getenv("SN_SCHUR_DEBUG")[0] == '2')
+                        fprintf(stderr, "[dbg] sweep %d step %d task %d lo %d n %d nb %d flags %d off %d: |U^TU-I| = %.3e\n",
+                            st.sweeps, t, k, htasks[k].lo, htasks[k].n, htasks[k].nb, htasks[k].flags, htasks[k].shift_off, worst);
+                }
+            }
             for (int k = 0; k < ntasks; k++)
                 apply_transform(htasks[k].lo, htasks[k].n,
                     ws.dU + (size_t)k * WS_MAX * WS_MAX, WS_MAX);
