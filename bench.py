@@ -3,9 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full reduction of one synthetic n x n matrix (the reference test
-driver's LCG input, seed 2019, generated directly in HBM; Q = I), inputs resident in
-HBM when the timed region starts.  Prints ONE JSON line (rank 0).
+One "step" = Hessenberg reduction + Schur reduction (Q accumulated through both) of one
+synthetic n x n matrix (the reference test driver's LCG input, seed 2019, generated
+directly in HBM; Q = I), inputs resident in HBM when the timed region starts.
+Prints ONE JSON line (rank 0).
 
 At N > 1 every rank reduces its own matrix on its own GPU (replicas, weak scaling):
 the block-column sharding of SURVEY.md section 8(e) is not built yet.
@@ -26,33 +27,42 @@ def hess_flops(n):
     return 16.0 / 3.0 * n ** 3      # 10/3 n^3 (A) + 2 n^3 (Q)
 
 
+def schur_flops(n):
+    return 25.0 * n ** 3            # Golub & Van Loan convention
+
+
 def cpu_baseline(n_sample):
     """The CPU oracle (kind "port": the restatement of the reference algorithm) timed on
     this host's cores on a bounded sample of the same workload (smaller n, same input
-    generator, same default panel width rule)."""
+    generator, same default panel width rule).  The Hessenberg leg runs OpenMP over all
+    cores; the Schur leg (double-shift QR restatement) is a scalar single-thread port."""
     import oracle as O
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(cores, 64)))
     A = O.random_fullpos(n_sample)
     Q = O.identity(n_sample)
     t0 = time.perf_counter()
     O.hessenberg(A, Q)
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    O.schur(A, Q)
+    t2 = time.perf_counter()
+    flops = hess_flops(n_sample) + schur_flops(n_sample)
     return {
-        "value": hess_flops(n_sample) / dt / 1e9, "unit": "GFLOP/s", "cores": cores,
-        "kind": "port",
-        "sample": f"oracle Hessenberg (16/3 n^3 flop) of the LCG matrix at n={n_sample}, "
-                  f"{dt:.1f} s, OpenMP over {cores} threads",
+        "value": flops / (t2 - t0) / 1e9, "unit": "GFLOP/s",
+        "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+        "sample": f"oracle Hessenberg+Schur of the LCG matrix at n={n_sample}: Hessenberg "
+                  f"{t1 - t0:.1f} s (OpenMP, {os.environ['OMP_NUM_THREADS']} threads), Schur "
+                  f"{t2 - t1:.1f} s (1 thread); same flop conventions (16/3+25) n^3",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--n", type=int, default=20000)
-    ap.add_argument("--cpu-n", type=int, default=2500, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=1500, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
@@ -94,7 +104,15 @@ def main():
         rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=sample_every)
         torch.cuda.synchronize()
         assert rc == 0
-        return time.perf_counter() - t0, st
+        t1 = time.perf_counter()
+        rc, real, imag, sst = S.schur_device(tA, tQ, n=n)
+        torch.cuda.synchronize()
+        assert rc == 0, f"schur rc={rc}"
+        t2 = time.perf_counter()
+        st["hessenberg_s"] = t1 - t0
+        st["schur_s"] = t2 - t1
+        st["schur"] = sst
+        return t2 - t0, st
 
     for _ in range(args.warmup):
         one_step(0)
@@ -118,7 +136,7 @@ def main():
 
     if rank == 0:
         ms_per_step = total / args.steps * 1e3
-        value = world * args.steps * hess_flops(n) / total / 1e9
+        value = world * args.steps * (hess_flops(n) + schur_flops(n)) / total / 1e9
         sm = sum(s["gemv_sampled_ms"] for s in stats)
         sb = sum(s["gemv_sampled_bytes"] for s in stats)
         nl = sum(s["gemv_sampled_launches"] for s in stats)
@@ -129,14 +147,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"Hessenberg reduction with Q accumulated, n={n}, LCG input seed 2019 "
-                            f"(BASELINE config 3 without its Schur leg, which is not built yet: "
-                            f"value = 16/3 n^3 flop / Hessenberg time)",
+                "workload": f"Hessenberg + multi-shift QR Schur, n={n}, Q accumulated, LCG input "
+                            f"seed 2019 (BASELINE config 3); value = (16/3 + 25) n^3 flop / time",
                 "n": n, "panel_width": S.default_panel_width(n),
                 "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
                 "residual_u": chk["residual_u"], "orthogonality_u": chk["orthogonality_u"],
                 "below_subdiagonal_nonzeros": chk["below_subdiagonal"],
-                "executed_gemm_tflop_per_step": stats[-1]["gemm_flops"] / 1e12,
+                "hessenberg_s": stats[-1]["hessenberg_s"], "schur_s": stats[-1]["schur_s"],
+                "hessenberg_gflops": hess_flops(n) / stats[-1]["hessenberg_s"] / 1e9,
+                "schur_sweeps": stats[-1]["schur"]["sweeps"], "schur_aeds": stats[-1]["schur"]["aeds"],
+                "executed_gemm_tflop_per_step":
+                    (stats[-1]["gemm_flops"] + stats[-1]["schur"]["gemm_flops"]) / 1e12,
             },
             "roofline": {
                 "kernel": "hess_gemv_kernel (panel y = A v, rows H2 of SURVEY 8a)",
