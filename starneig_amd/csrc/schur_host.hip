@@ -12,6 +12,9 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace sn { namespace host {
 
@@ -480,6 +483,10 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     double thres, double *spike, double *sr, double *si)
 {
     AedResult res{0, 0, 0};
+    static const bool prof = getenv("SN_AED_PROFILE") != nullptr;
+    static double t_schur = 0, t_reorder = 0, t_hess = 0; static int calls = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     for (int j = 0; j < nw; j++) for (int i = 0; i < nw; i++) Z_(i, j) = (i == j) ? 1.0 : 0.0;
     std::vector<double> wr(nw), wi(nw);
     int info = small_schur(nw, T, ldt, Z, ldz, wr.data(), wi.data());
@@ -489,6 +496,7 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
         roof = info;
         res.failed = 1;
     }
+    double t1 = now();
     const double ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)nw / ulp);
     int top = roof;           // undeflatable blocks accumulate in [roof, top)
     int i = nw - 1;
@@ -515,6 +523,7 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
             top += bs;
         }
     }
+    double t2 = now();
     res.deflated = nw - top;
     int ns = top;
     // shifts from the undeflated part; "extract something" if it is too small (:3000-3010)
@@ -553,6 +562,12 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
             }
         }
         hessenberg_small(nw, ns, T, ldt, Z, ldz);
+    }
+    if (prof) {
+        t_schur += t1 - t0; t_reorder += t2 - t1; t_hess += now() - t2; calls++;
+        if (calls % 20 == 0)
+            fprintf(stderr, "[aed] calls %d schur %.2fs reorder %.2fs hess %.2fs (nw %d)\n",
+                calls, t_schur, t_reorder, t_hess, nw);
     }
     return res;
 }
