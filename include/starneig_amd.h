@@ -31,7 +31,8 @@ starneig_error_t starneig_amd_hessenberg_device(
  * Hessenberg matrix: dH <- real Schur form, dQ <- dQ*U (dQ may be NULL).  real/imag are
  * HOST arrays of length n (both NULL = not extracted).  conf may be NULL (defaults).
  * stats (may be NULL) is double[8]: [0] total ms, [1] QR sweeps, [2] AED calls,
- * [3] small host solves, [4] chase launches, [5] executed GEMM flops.
+ * [3] small host solves, [4] chase launches, [5] executed GEMM flops, [6] seconds inside
+ * the host AED kernel, [7] seconds the host waited for the GPU.
  * Returns STARNEIG_DID_NOT_CONVERGE like schur/core.c:2324-2326. */
 struct starneig_schur_conf;
 starneig_error_t starneig_amd_schur_device(

@@ -8,6 +8,7 @@ n = int(sys.argv[1])
 tA0 = S.device_matrix(n); S.lcg_fill_device(tA0, n, n)
 tH = tA0.clone(); tQ0 = S.device_matrix(n); S.set_matrix_device(tQ0, n, n, 0.0, 1.0)
 rc, hst = S.hessenberg_device(tH, tQ0, n=n, stats=True)
+torch.cuda.synchronize()
 print("hess %.2fs" % (hst["total_ms"]/1e3), flush=True)
 for cfg in sys.argv[2:]:
     aed, ns, small = [int(x) for x in cfg.split(",")]
@@ -17,4 +18,4 @@ for cfg in sys.argv[2:]:
     rc, real, imag, st = S.schur_device(tA, tQ, n=n, conf=conf)
     torch.cuda.synchronize(); dt=time.time()-t
     rc2, chk = S.check_device(tQ, tA, tA0, n=n)
-    print(cfg, "rc", rc, "%.2fs"%dt, "sweeps", st["sweeps"], "aeds", st["aeds"], "chase", st["chase_launches"], "gemmTF %.1f"%(st["gemm_flops"]/1e12), "res %.0f orth %.0f"%(chk["residual_u"], chk["orthogonality_u"]), flush=True)
+    print(cfg, "rc", rc, "%.2fs"%dt, "sweeps", st["sweeps"], "aeds", st["aeds"], "chase", st["chase_launches"], "gemmTF %.1f"%(st["gemm_flops"]/1e12), "aed_host %.2fs wait %.2fs"%(st["aed_host_s"], st["gpu_wait_s"]), "res %.0f orth %.0f"%(chk["residual_u"], chk["orthogonality_u"]), flush=True)

@@ -301,6 +301,7 @@ SN_API starneig_error_t starneig_amd_schur_device(
     if (stats) {
         stats[0] = st.total_ms; stats[1] = st.sweeps; stats[2] = st.aeds;
         stats[3] = st.small_solves; stats[4] = st.chase_launches; stats[5] = st.gemm_flops;
+        stats[6] = st.aed_host_s; stats[7] = st.wait_s;
     }
     return rc;
 }

@@ -28,6 +28,12 @@ void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
     double alpha, double const *A, int lda, double const *B, int ldb,
     double beta, double *C, int ldc);
 
+struct GemmDesc {               // one problem of a batched launch (device pointers)
+    double const *A; double const *B; double *C;
+    int m, n, k, lda, ldb, ldc;
+};
+void dgemm_batched_left_inplace(hipStream_t s, GemmDesc const *ddescs, int count, int max_cols);
+void dgemm_batched_right_inplace(hipStream_t s, GemmDesc const *ddescs, int count, int max_rows);
 void dgemm_left_inplace(hipStream_t s, int w, int ncols, double const *U, int ldu,
     double *X, int ldx);
 void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int ldu,
@@ -75,6 +81,8 @@ struct SchurStats {
     int sweeps = 0, aeds = 0, small_solves = 0, chase_launches = 0;
     double gemm_flops = 0.0;
     float total_ms = 0.f;
+    double aed_host_s = 0.0;    // wall time inside the host AED kernel
+    double wait_s = 0.0;        // wall time the host waited for the GPU (window downloads)
 };
 // Reduces the device-resident upper Hessenberg matrix dH to real Schur form, dQ <- dQ*U.
 // real/imag are HOST arrays (may be NULL).  Returns a starneig_error_t value.

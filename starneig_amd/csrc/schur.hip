@@ -15,10 +15,12 @@
 // (schur/tasks.c:203-261 have no .cuda_funcs).
 #include "common.h"
 #include "schur_host.h"
+#include "dgemm_tile.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
+#include <chrono>
 #include <starneig/error.h>
 
 namespace sn {
@@ -30,6 +32,9 @@ constexpr int WS_MAX = 96;          // diagonal window (rows) held in LDS
 constexpr int NB_MAX = 15;          // bulges per chain: 3*NB_MAX+1 <= WS_MAX/2 + ...
 constexpr int LDW = WS_MAX + 1;     // odd leading dimension: conflict-free row AND column walks
 constexpr int TASK_RING = 32;      // pinned task lists in flight
+constexpr int CHASE_THREADS = 1024; // 16 waves share one window
+constexpr int UPDATE_LDS_BYTES_L = GemmCfg<128, 128, 16, true, false>::LDS_BYTES;
+constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, 128, 16, false, false>::LDS_BYTES;
 constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 8 * NB_MAX + 16) * 8;
 
 struct ChaseTask {
@@ -40,6 +45,33 @@ struct ChaseTask {
     int flags;      // 1 = introduce, 2 = finalize
     int right;      // column where the trailing bulge of the chain stops (non-finalize windows)
 };
+
+// One step of a sweep: every chain in flight advances by one window.  The window of the
+// k-th active chain is a pure function of these integers, so the chase kernel and the update
+// kernels derive it on the device (no per-step task upload).
+struct SweepStep {
+    int ilo, ihi;           // active block
+    int ws, nbc, adv, gap;  // window size, bulges per chain, columns per step, steps between chains
+    int nbulges;            // total bulges of the sweep
+    int steps_per_chain;
+    int t;                  // step index
+    int cmin, ntasks;       // chains cmin .. cmin+ntasks-1 are in flight
+};
+
+__host__ __device__ inline ChaseTask make_task(SweepStep const &st, int k)
+{
+    int const c = st.cmin + k, p = st.t - c * st.gap;
+    ChaseTask task;
+    task.lo = st.ilo + p * st.adv;
+    int const rem = st.nbulges - c * st.nbc;
+    task.nb = rem < st.nbc ? rem : st.nbc;
+    task.shift_off = 2 * c * st.nbc;
+    task.flags = (p == 0) ? 1 : 0;
+    if (task.lo + st.ws >= st.ihi) { task.flags |= 2; task.n = st.ihi - task.lo; }
+    else task.n = st.ws;
+    task.right = st.adv;
+    return task;
+}
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
 __device__ __forceinline__ void shift_vector(double const *W, double sr1, double si1,
@@ -85,18 +117,18 @@ __device__ __forceinline__ void small_reflector(int len, double const *x,
 // (2) all lanes apply the reflectors from the left, (3) from the right to the window and
 // to the accumulated factor U.  Bulges sit 3 columns apart, so the reflectors of one step
 // touch disjoint rows/columns and commute (the LAPACK dlaqr5 argument).
-__global__ __launch_bounds__(256)
-void schur_chase_kernel(ChaseTask const *__restrict__ tasks, double *__restrict__ H, int ldH,
+__global__ __launch_bounds__(CHASE_THREADS)
+void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *W = lds, *U = lds + WS_MAX * LDW, *R = U + WS_MAX * LDW;   // R: per bulge {v1,v2,tau,row0|len}
     int *Ri = reinterpret_cast<int *>(R + 4 * NB_MAX);
-    ChaseTask const t = tasks[blockIdx.x];
+    ChaseTask const t = make_task(step, blockIdx.x);
     int const n = t.n, nb = t.nb, tid = threadIdx.x;
     bool const introduce = t.flags & 1, finalize = t.flags & 2;
 
-    for (int idx = tid; idx < n * n; idx += 256) {
+    for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         W[c * LDW + r] = H[(size_t)(t.lo + c) * ldH + t.lo + r];
         U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
@@ -131,7 +163,7 @@ void schur_chase_kernel(ChaseTask const *__restrict__ tasks, double *__restrict_
         }
         __syncthreads();
         // (2) left: rows row0..row0+len-1, columns max(row0,0)..n-1   (row0 = j+1)
-        for (int item = tid; item < nb * n; item += 256) {
+        for (int item = tid; item < nb * n; item += CHASE_THREADS) {
             int const i = item / n, c = item - i * n;
             int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
             if (len == 0 || c < row0) continue;
@@ -144,7 +176,7 @@ void schur_chase_kernel(ChaseTask const *__restrict__ tasks, double *__restrict_
         }
         __syncthreads();
         // (3) right: columns row0..row0+len-1; window rows 0..min(n-1,row0+3), all rows of U
-        for (int item = tid; item < nb * n * 2; item += 256) {
+        for (int item = tid; item < nb * n * 2; item += CHASE_THREADS) {
             int const i = item / (2 * n), rr = item - i * 2 * n;
             int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
             if (len == 0) continue;
@@ -162,10 +194,40 @@ void schur_chase_kernel(ChaseTask const *__restrict__ tasks, double *__restrict_
     }
 
     double *Uo = Uout + (size_t)blockIdx.x * WS_MAX * WS_MAX;
-    for (int idx = tid; idx < n * n; idx += 256) {
+    for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         H[(size_t)(t.lo + c) * ldH + t.lo + r] = W[c * LDW + r];
         Uo[c * WS_MAX + r] = U[c * LDW + r];
+    }
+}
+
+// Off-diagonal updates of all chains of one step (row S3): MODE 0: H(win, right of win) <-
+// U^T ., MODE 1: H(above win, win) <- . U and (blockIdx.y >= ntasks) Q(:, win) <- . U.
+// One workgroup owns all w <= 128 rows (columns) of its tile and reads its whole operand
+// panel before the epilogue writes, so the update is done in place.
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U)
+{
+    int const k = blockIdx.y % step.ntasks;
+    bool const is_q = (int)blockIdx.y >= step.ntasks;
+    ChaseTask const t = make_task(step, k);
+    double const *Uk = U + (size_t)k * WS_MAX * WS_MAX;
+    int const w = t.n, lo = t.lo;
+    if (MODE == 0) {
+        int const ncols = n - (lo + w);
+        if ((int)blockIdx.x * 128 >= ncols) return;
+        double *X = H + (size_t)(lo + w) * ldH + lo;
+        gemm_tile<128, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH,
+            0, blockIdx.x);
+    } else {
+        int const rows = is_q ? n : lo;
+        if ((int)blockIdx.x * 128 >= rows) return;
+        double *X = is_q ? Q + (size_t)lo * ldQ : H + (size_t)lo * ldH;
+        int const ld = is_q ? ldQ : ldH;
+        gemm_tile<128, 128, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, WS_MAX, 0.0, X, ld,
+            blockIdx.x, 0);
     }
 }
 
@@ -207,6 +269,7 @@ struct SchurWorkspace {
     int n = 0, nwmax = 0, max_chains = 0;
     double *dU = nullptr;           // max_chains x WS_MAX x WS_MAX
     ChaseTask *dTasks = nullptr;
+    GemmDesc *dDescs = nullptr, *hDescs = nullptr;
     double *dShiftR = nullptr, *dShiftI = nullptr;
     double *dSub = nullptr;         // n
     double *dWin = nullptr, *dZ = nullptr, *dTmp = nullptr;   // nwmax^2, nwmax^2, n*nwmax
@@ -216,10 +279,10 @@ struct SchurWorkspace {
     bool attr_set = false;
 
     void release() {
-        void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dShiftR, (void **)&dShiftI,
+        void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dDescs, (void **)&dShiftR, (void **)&dShiftI,
             (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
-        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hTasks};
+        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hTasks, (void **)&hDescs};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
         n = nwmax = max_chains = 0;
     }
@@ -228,7 +291,6 @@ struct SchurWorkspace {
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
         SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)max_chains * WS_MAX * WS_MAX * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dTasks, (size_t)TASK_RING * max_chains * sizeof(ChaseTask)));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
@@ -239,10 +301,13 @@ struct SchurWorkspace {
         SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)nwmax * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)nwmax * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hTasks, (size_t)TASK_RING * max_chains * sizeof(ChaseTask), hipHostMallocDefault));
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<0>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<1>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
             attr_set = true;
         }
     }
@@ -263,6 +328,11 @@ static int lapack_min_shifts(int n)
 }
 
 namespace {
+
+static inline double wall()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct Driver {
     hipStream_t s;
@@ -304,9 +374,11 @@ struct Driver {
 
     void download_window(int lo, int w, double *h, int ldh)
     {
+        double t0 = wall();
         SN_HIP_CHECK(hipMemcpy2DAsync(h, (size_t)ldh * 8, H + (size_t)lo * ldH + lo, (size_t)ldH * 8,
             (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
+        st.wait_s += wall() - t0;
     }
     void upload_window(int lo, int w, double const *h, int ldh)
     {
@@ -357,74 +429,29 @@ struct Driver {
         if (size <= WS_MAX) steps_per_chain = 1;
         else steps_per_chain = divceil(size - ws_, adv) + 1;
         int const total_steps = steps_per_chain + (chains - 1) * gap;
+        SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
         for (int t = 0; t < total_steps; t++) {
-            // ring of pinned task lists so the host can run ahead of the stream
-            int const slot = ring_pos++ % TASK_RING;
-            if (slot == 0 && ring_pos > 1) SN_HIP_CHECK(hipStreamSynchronize(s));
-            ChaseTask *htasks = ws.hTasks + (size_t)slot * ws.max_chains;
-            ChaseTask *dtasks = ws.dTasks + (size_t)slot * ws.max_chains;
-            int ntasks = 0;
-            for (int c = 0; c < chains; c++) {
-                int p = t - c * gap;
-                if (p < 0 || p >= steps_per_chain) continue;
-                ChaseTask &task = htasks[ntasks];
-                task.lo = ilo + p * adv;
-                task.nb = std::min(nbc, nbulges - c * nbc);
-                task.shift_off = 2 * c * nbc;
-                task.flags = 0;
-                if (p == 0) task.flags |= 1;
-                if (task.lo + ws_ >= ihi) { task.flags |= 2; task.n = ihi - task.lo; }
-                else task.n = ws_;
-                task.right = adv;
-                ntasks++;
-            }
-            if (ntasks == 0) continue;
-            SN_HIP_CHECK(hipMemcpyAsync(dtasks, htasks, (size_t)ntasks * sizeof(ChaseTask),
-                hipMemcpyHostToDevice, s));
-            std::vector<double> dbg_win;
-            if (getenv("SN_SCHUR_DEBUG")) {
-                SN_HIP_CHECK(hipStreamSynchronize(s));
-                dbg_win.resize((size_t)ntasks * WS_MAX * WS_MAX);
-                for (int k = 0; k < ntasks; k++)
-                    SN_HIP_CHECK(hipMemcpy2D(dbg_win.data() + (size_t)k * WS_MAX * WS_MAX, WS_MAX * 8,
-                        H + (size_t)htasks[k].lo * ldH + htasks[k].lo, (size_t)ldH * 8,
-                        (size_t)htasks[k].n * 8, htasks[k].n, hipMemcpyDeviceToHost));
-            }
-            hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(256), CHASE_LDS_BYTES, s,
-                dtasks, H, ldH, ws.dU, ws.dShiftR, ws.dShiftI);
+            int cmin = (t - steps_per_chain + 1 + gap - 1) / gap;      // ceil for positives
+            if (t - steps_per_chain + 1 <= 0) cmin = 0;
+            int const cmax = std::min(chains - 1, t / gap);
+            if (cmax < cmin) continue;
+            step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
+            int const ntasks = step.ntasks;
+            hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
+                step, H, ldH, ws.dU, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
-            if (getenv("SN_SCHUR_DEBUG")) {
-                SN_HIP_CHECK(hipStreamSynchronize(s));
-                std::vector<double> hu((size_t)WS_MAX * WS_MAX);
-                for (int k = 0; k < ntasks; k++) {
-                    SN_HIP_CHECK(hipMemcpy(hu.data(), ws.dU + (size_t)k * WS_MAX * WS_MAX,
-                        hu.size() * 8, hipMemcpyDeviceToHost));
-                    int w = htasks[k].n; double worst = 0.0;
-                    for (int a = 0; a < w; a++) for (int b = 0; b < w; b++) {
-                        double dot = 0.0;
-                        for (int r = 0; r < w; r++) dot += hu[(size_t)a * WS_MAX + r] * hu[(size_t)b * WS_MAX + r];
-                        worst = std::max(worst, std::fabs(dot - (a == b ? 1.0 : 0.0)));
-                    }
-                    if (worst > 1e-12) {
-                        FILE *f = fopen("gpurun_out/bad_window.bin", "wb");
-                        if (f) {
-                            int hdr[4] = {htasks[k].n, htasks[k].nb, htasks[k].flags, htasks[k].right};
-                            fwrite(hdr, sizeof(int), 4, f);
-                            fwrite(dbg_win.data() + (size_t)k * WS_MAX * WS_MAX, 8, (size_t)WS_MAX * WS_MAX, f);
-                            fwrite(sr + htasks[k].shift_off, 8, 2 * htasks[k].nb, f);
-                            fwrite(si + htasks[k].shift_off, 8, 2 * htasks[k].nb, f);
-                            fwrite(hu.data(), 8, hu.size(), f);
-                            fclose(f);
-                        }
-                    }
-                    if (worst > 1e-12 || getenv("SN_SCHUR_DEBUG")[0] == '2')
-                        fprintf(stderr, "[dbg] sweep %d step %d task %d lo %d n %d nb %d flags %d off %d: |U^TU-I| = %.3e\n",
-                            st.sweeps, t, k, htasks[k].lo, htasks[k].n, htasks[k].nb, htasks[k].flags, htasks[k].shift_off, worst);
-                }
+            int max_cols = 0;
+            for (int k = 0; k < ntasks; k++) {
+                ChaseTask const tk = make_task(step, k);
+                int const rc = n - (tk.lo + tk.n);
+                max_cols = std::max(max_cols, rc);
+                st.gemm_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
             }
-            for (int k = 0; k < ntasks; k++)
-                apply_transform(htasks[k].lo, htasks[k].n,
-                    ws.dU + (size_t)k * WS_MAX * WS_MAX, WS_MAX);
+            if (max_cols > 0)
+                hipLaunchKernelGGL(schur_update_kernel<0>, dim3(divceil(max_cols, 128), ntasks), dim3(256),
+                    UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, ws.dU);
+            hipLaunchKernelGGL(schur_update_kernel<1>, dim3(divceil(n, 128), Q ? 2 * ntasks : ntasks),
+                dim3(256), UPDATE_LDS_BYTES_R, s, step, H, ldH, Q, ldQ, n, ws.dU);
         }
         st.sweeps++;
     }
@@ -439,10 +466,11 @@ int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
     int const min_val = lapack_min_shifts(n);
     int nw_default = (int)std::max(min_val / 0.7, 0.08 * n);
     int ns_default = (int)std::max((double)min_val, 0.06 * n);
-    // the AED window is reduced on the host in this revision: cap the defaults at the LAPACK
-    // sizes (384/256); explicit conf values are honoured up to 1024
-    nw_default = std::min(nw_default, 384);
-    ns_default = std::min(ns_default, 256);
+    // the AED window is reduced on the host in this revision (O(w^3) scalar work per call):
+    // the measured optimum at n = 20000 is 192 / 128 (8.2 s vs 19.6 s at 384 / 256);
+    // explicit conf values are honoured up to 1024
+    nw_default = std::min(nw_default, 192);
+    ns_default = std::min(ns_default, 128);
     int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 1024) : nw_default;
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : ns_default;
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
@@ -482,8 +510,10 @@ int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
         hipLaunchKernelGGL(schur_scan_subdiag_kernel, dim3(divceil(std::max(ihi - 1, 1), 256)), dim3(256),
             0, s, 0, ihi, dH, ldH, thres, ws.dSub, n);
         if (ihi > 1) {
+            double tw = wall();
             SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
             SN_HIP_CHECK(hipStreamSynchronize(s));
+            d.st.wait_s += wall() - tw;
         }
         int ilo = ihi - 1;
         while (ilo > 0 && ws.hSub[ilo - 1] != 0.0) ilo--;
@@ -509,8 +539,10 @@ int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
         double sub = 0.0;
         if (kw > ilo) sub = ws.hSub[kw - 1];
         d.download_window(kw, nw, ws.hWin, nw);
+        double t_aed0 = wall();
         host::AedResult ar = host::aed_window(nw, ws.hWin, nw, ws.hZ, nw, sub, thres,
             spike.data(), sr.data(), si.data());
+        d.st.aed_host_s += wall() - t_aed0;
         d.st.aeds++;
         if (ar.deflated > 0) {
             d.upload_window(kw, nw, ws.hWin, nw);

@@ -219,7 +219,8 @@ def schur_device(tH, tQ, n=None, conf=None, eigenvalues=True):
         None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data,
         C.byref(conf) if conf is not None else None, _stream_ptr(), st)
     stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
-             "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5]}
+             "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
+             "aed_host_s": st[6], "gpu_wait_s": st[7]}
     return rc, real, imag, stats
 
 
