@@ -23,6 +23,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic_ratio():
+    """HBM traffic / algorithmic bytes of the panel gemv from the committed PMC passes
+    (profiles/r1_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_gemv_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_over_algorithmic"]
+    except Exception:
+        return None
+
+
 def hess_flops(n):
     return 16.0 / 3.0 * n ** 3      # SURVEY.md section 8(d): 10/3 n^3 (A) + 2 n^3 (Q)
 
@@ -141,6 +152,7 @@ def main():
         sb = sum(s["gemv_sampled_bytes"] for s in stats)
         nl = sum(s["gemv_sampled_launches"] for s in stats)
         achieved = sb / (sm * 1e-3) / 1e9 if sm > 0 else None
+        ratio = pmc_traffic_ratio()
         out = {
             "metric": "GFLOP/s Hessenberg+Schur, n=20000 real dense, 1/2/4/8 MI355X; residual",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -162,7 +174,11 @@ def main():
             "roofline": {
                 "kernel": "hess_gemv_kernel (panel y = A v, rows H2 of SURVEY 8a)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": (ratio * sb / nl) if (ratio and nl) else None,
+                "traffic_note": "avg algorithmic bytes per launch x PMC ratio "
+                                "(2*FETCH_SIZE+WRITE_SIZE)/algorithmic measured on the 312 "
+                                "first-panel launches at n=20000, profiles/r1_gemv_pmc_traffic.json",
                 "launches_timed": nl,
                 "avg_launch_us": (sm / nl * 1e3) if nl else None,
                 "avg_launch_bytes": (sb / nl) if nl else None,

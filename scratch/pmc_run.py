@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import starneig_amd as S
+torch.cuda.set_device(0); torch.zeros(1, device="cuda")
+S.node_init(1,1,S.NO_MESSAGES)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+tA = S.device_matrix(n); S.lcg_fill_device(tA, n, n)
+tQ = S.device_matrix(n); S.set_matrix_device(tQ, n, n, 0.0, 1.0)
+rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=1)
+print(rc, st, "GB/s sampled", st["gemv_sampled_bytes"]/st["gemv_sampled_ms"]/1e6)

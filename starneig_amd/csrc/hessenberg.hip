@@ -485,8 +485,11 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
     SN_HIP_CHECK(hipEventRecord(ws.entry, caller));
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.entry, 0));
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
+    // profiling aid: stop after k panels (PMC runs cannot take 60 k dispatches); the result
+    // is then a partial reduction and must not be used
+    int const max_panels = getenv("SN_HESS_MAX_PANELS") ? atoi(getenv("SN_HESS_MAX_PANELS")) : 1 << 30;
     int pcount = 0;
-    for (int i = begin; i < end - 1; i += panel_width, pcount++) {
+    for (int i = begin; i < end - 1 && pcount < max_panels; i += panel_width, pcount++) {
         int const nb = std::min(panel_width, end - i - 1);
         int const R0 = i + 1, E = end, m = E - R0;
         int const buf = pcount & 1;
