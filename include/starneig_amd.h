@@ -26,6 +26,24 @@ starneig_error_t starneig_amd_hessenberg_device(
     int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, void *stream, double *stats);
 
+/* Block-column sharded Hessenberg reduction over the GPUs of one node, one process per
+ * GPU (the reference's distributed counterpart is the StarPU-MPI path,
+ * hessenberg/tasks.c:337-345, mpi/interface_hessenberg.c:150-195).  Every rank passes
+ * full-size dA/dQ holding the same input and gets the full result back.  The caller owns
+ * the communication: it allocates dY (ld doubles), dP (ld*panel_width) and dW (w_capacity
+ * >= n*panel_width doubles), ld = starneig_amd_hessenberg_panel_ld(n, panel_width), and
+ * supplies allreduce_sum / broadcast callbacks that act on (buffer, offset, count) with
+ * buffer 0 = dY, 1 = dP, 2 = dW, 3 = dA, 4 = dQ, ordered on `stream`
+ * (torch.distributed over RCCL in starneig_amd/distributed.py). */
+int starneig_amd_hessenberg_panel_ld(int n, int panel_width);
+starneig_error_t starneig_amd_hessenberg_sharded_device(
+    int n, int panel_width, double *dA, int ldA, double *dQ, int ldQ,
+    double *dY, double *dP, double *dW, long w_capacity,
+    int rank, int world,
+    void (*allreduce_sum)(void *ctx, int buffer, long offset, long count),
+    void (*broadcast)(void *ctx, int buffer, long offset, long count, int root),
+    void *ctx, void *stream, double *stats);
+
 /* Replaces starneig_schur_insert_tasks (schur/core.c:2342-2514) + the window and update
  * codelets (schur/cpu.c, cpu_utils.c, common/cpu.c:54-162) on a device-resident upper
  * Hessenberg matrix: dH <- real Schur form, dQ <- dQ*U (dQ may be NULL).  real/imag are

@@ -333,6 +333,41 @@ SN_API starneig_error_t starneig_amd_hessenberg_device(
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 }
 
+SN_API int starneig_amd_hessenberg_panel_ld(int n, int panel_width)
+{
+    if (panel_width <= 0) panel_width = default_panel_width(n);
+    return sn::hessenberg_panel_ld(n, panel_width);
+}
+
+SN_API starneig_error_t starneig_amd_hessenberg_sharded_device(
+    int n, int panel_width, double *dA, int ldA, double *dQ, int ldQ,
+    double *dY, double *dP, double *dW, long w_capacity,
+    int rank, int world,
+    void (*allreduce_sum)(void *ctx, int buffer, long offset, long count),
+    void (*broadcast)(void *ctx, int buffer, long offset, long count, int root),
+    void *ctx, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (dA == NULL)            return -3;
+    if (ldA < n)               return -4;
+    if (dQ != NULL && ldQ < n) return -6;
+    if (dY == NULL || dP == NULL || dW == NULL) return STARNEIG_INVALID_ARGUMENTS;
+    if (world < 1 || rank < 0 || rank >= world || !allreduce_sum || !broadcast)
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    if (panel_width <= 0) panel_width = default_panel_width(n);
+    if (panel_width < 8) return STARNEIG_INVALID_CONFIGURATION;
+    sn::HessComm comm{rank, world, allreduce_sum, broadcast, ctx};
+    sn::HessenbergTimings tm;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = sn::hessenberg_sharded_device(s, n, panel_width, dA, ldA, dQ, ldQ, dY, dP, dW,
+        w_capacity, comm, stats ? &tm : nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    if (stats) { stats[0] = tm.total_ms; stats[1] = tm.gemv_bytes; stats[2] = tm.gemm_flops;
+                 stats[5] = (double)tm.gemv_launches; }
+    return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
+}
+
 SN_API starneig_error_t starneig_amd_dgemm_device(
     char transA, char transB, int m, int n, int k, double alpha,
     double const *dA, int ldA, double const *dB, int ldB, double beta,

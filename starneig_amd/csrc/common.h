@@ -68,6 +68,20 @@ struct HessenbergTimings {
 int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *timings);
 
+// Collective callbacks of the sharded reduction.  buffer ids: 0 = y vector, 1 = panel P,
+// 2 = W scratch, 3 = A, 4 = Q (all allocated by the caller, who maps the id to its handle).
+struct HessComm {
+    int rank, world;
+    void (*allreduce_sum)(void *ctx, int buffer, long offset, long count);
+    void (*broadcast)(void *ctx, int buffer, long offset, long count, int root);
+    void *ctx;
+};
+int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
+    double *dA, int ldA, double *dQ, int ldQ,
+    double *dYsum, double *dP, double *dW2, long w2_capacity,
+    HessComm const &comm, HessenbergTimings *timings);
+int hessenberg_panel_ld(int n, int panel_width);
+
 // ---- Schur (schur.hip) -----------------------------------------------------------
 struct SchurParams {            // resolved from starneig_schur_conf (negative = default)
     int iteration_limit = -1;

@@ -285,7 +285,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double const *__restrict__ P, int R0, int E, int j, int cols_per_split, int ldp,
     int nshadow, int row_tiles,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
-    double *__restrict__ acc, double *__restrict__ scal)
+    double *__restrict__ acc, double *__restrict__ scal, int world, int rank)
 {
     __shared__ double s_wv[MAXJ], s_t[NGS][RBS + 1], s_scal[2];
     int const piv = R0 + j, par = j & 1;
@@ -339,8 +339,18 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
 
     int const b = blockIdx.x - nshadow;
     int const tile = b % row_tiles, split = b / row_tiles;
-    int const c_begin = piv + split * cols_per_split;
-    int const c_end = min(E, c_begin + cols_per_split);
+    int c_begin, c_end;
+    if (rank < 0) {
+        c_begin = piv + split * cols_per_split;
+        c_end = min(E, c_begin + cols_per_split);
+    } else {
+        // block-column shards: this rank streams only the column blocks it owns
+        // (block b = c / cols_per_split belongs to rank b % world); split s = its s-th block
+        int const b0 = piv / cols_per_split;
+        int const B = b0 + ((rank - b0 % world) + world) % world + split * world;
+        c_begin = max(piv, B * cols_per_split);
+        c_end = min(E, (B + 1) * cols_per_split);
+    }
     double *yp = ypart + (size_t)split * ldp;
     if (ALIGNED) {
         int const g = (R0 & ~1) + tile * GEMV_ROWS + threadIdx.x * 2;
@@ -454,6 +464,8 @@ static HessWorkspace g_ws;
 
 void hessenberg_release_workspace() { g_ws.release(); }
 
+int hessenberg_panel_ld(int n, int) { return (int)roundup((size_t)n + GEMV_ROWS + 16, 128); }
+
 static void choose_split(int m_rows, int ncols, int *nsplit, int *cps)
 {
     int row_tiles = divceil(m_rows + 1, GEMV_ROWS);
@@ -528,10 +540,10 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             dim3 grid(nshadow + row_tiles * nsplit);
             if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal);
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
             else
                 hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal);
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
             if (sampled) {
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
                 ws.sample_bytes.push_back(8.0 * (double)m * (double)ncols);
@@ -602,6 +614,178 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             tm->sampled_ms += t;
             tm->sampled_bytes += ws.sample_bytes[k];
         }
+    }
+    return 0;
+}
+
+// ---- block-column sharded reduction over several GPUs (BASELINE config 4) -----
+// One process per GPU; every rank holds full-size A and Q buffers but only MAINTAINS the
+// column blocks of A it owns (block b of `cb` = panel_width columns belongs to rank
+// b % world) and its contiguous row block of Q.  Per panel: the owner's panel columns are
+// broadcast; the column chain (colA/colC and the shadow work) is replicated on every rank;
+// the HBM-bound gemv is sharded by column block and the partial y vectors are summed by
+// one all-reduce per column; the trailing updates touch owned blocks only; the update of
+// the rows above the panel needs one all-reduce of W = A(0:i+1, .) V T per panel.  At the
+// end the pieces are assembled on every rank (zero the unowned parts, all-reduce).
+// Collectives are issued through callbacks (torch.distributed = RCCL in production) on
+// buffers the caller allocated; everything runs on the caller's stream so that the
+// collectives are ordered with the kernels.
+__global__ void hess_ysum_kernel(int R0, int E, int nsplit, int ldp,
+    double const *__restrict__ ypart, double *__restrict__ ysum)
+{
+    int g = R0 + blockIdx.x * 256 + threadIdx.x;
+    if (g >= E) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; k++) s += ypart[(size_t)k * ldp + g];
+    ysum[g] = s;
+}
+
+// zero the columns of A this rank does not own (mode 0) / the rows of Q it does not own (mode 1)
+__global__ void hess_zero_unowned_kernel(int mode, int n, double *__restrict__ X, int ld,
+    int cb, int world, int rank, int row_lo, int row_hi)
+{
+    int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    for (int c = blockIdx.y; c < n; c += gridDim.y) {
+        bool keep = mode == 0 ? ((c / cb) % world == rank) : (r >= row_lo && r < row_hi);
+        if (!keep) X[(size_t)c * ld + r] = 0.0;
+    }
+}
+
+int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
+    double *dA, int ldA, double *dQ, int ldQ,
+    double *dYsum, double *dP, double *dW2, long w2_capacity,
+    HessComm const &comm, HessenbergTimings *tm)
+{
+    if (panel_width > MAXJ - 8) panel_width = MAXJ - 8;
+    int const world = comm.world, rank = comm.rank, cb = panel_width;
+    HessWorkspace &ws = g_ws;
+    if (ws.n != n) ws.release();        // the caller sized its buffers with hessenberg_panel_ld(n)
+    ws.ensure(n, panel_width);
+    int const ldp = ws.ldp;
+    bool const aligned = (ldA % 2 == 0) && (((uintptr_t)dA) % 16 == 0);
+    int const begin = 0, end = n;
+    double gemv_bytes = 0.0, gemm_flops = 0.0;
+    long gemv_launches = 0;
+    // contiguous row block of Q owned by this rank (multiples of 128 rows)
+    int const qchunk = (int)roundup(divceil(n, world), 128);
+    int const q_lo = std::min(n, rank * qchunk), q_hi = std::min(n, (rank + 1) * qchunk);
+    if ((long)n * panel_width > w2_capacity) return -1;
+
+    if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
+    int pcount = 0;
+    double *V = ws.V[0], *VT = ws.VT[0];
+    for (int i = begin; i < end - 1; i += panel_width, pcount++) {
+        int const nb = std::min(panel_width, end - i - 1);
+        int const R0 = i + 1, E = end, m = E - R0;
+        int const nwg = divceil(m, RB);
+        int const owner = (i / cb) % world;
+
+        SN_HIP_CHECK(hipMemsetAsync(ws.acc, 0, (size_t)ACC_TOTAL * sizeof(double), s));
+        // panel columns from their owner (the caller's dP is the panel buffer of every rank)
+        hipLaunchKernelGGL(hess_copy_in_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
+            R0, E, nb, i, dA, ldA, dP, ldp);
+        comm.broadcast(comm.ctx, 1, 0, (long)ldp * nb, owner);
+
+        // owned column blocks that intersect [piv, E): splits of the sharded gemv
+        for (int j = 0; j < nb; j++) {
+            int const piv = R0 + j;
+            if (j > 0)
+                hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(256), 0, s,
+                    R0, E, j, ldp, dP, V, VT, ws.Y, dYsum, 1, ws.acc, ws.scal);
+            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(256), 0, s,
+                R0, E, j, ldp, dP, V, ws.acc);
+            int const b0 = piv / cb;
+            int const first = b0 + ((rank - b0 % world) + world) % world;
+            int const last_block = (E - 1) / cb;
+            int nsplit = first > last_block ? 0 : (last_block - first) / world + 1;
+            int const row_tiles = divceil(E - (R0 & ~1), GEMV_ROWS);
+            int const nshadow = divceil(m, RBS);
+            // ypart has MAX_SPLIT slots: with more owned blocks than that the tail blocks are
+            // merged by widening the block (never happens for n/cb/world <= 32)
+            if (nsplit > MAX_SPLIT) return -2;
+            dim3 grid(nshadow + row_tiles * std::max(nsplit, 0));
+            if (aligned)
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    world, rank);
+            else
+                hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    world, rank);
+            hipLaunchKernelGGL(hess_ysum_kernel, dim3(divceil(m, 256)), dim3(256), 0, s,
+                R0, E, nsplit, ldp, ws.ypart, dYsum);
+            comm.allreduce_sum(comm.ctx, 0, R0, (long)m);
+            gemv_launches++;
+            gemv_bytes += 8.0 * (double)m * (double)(E - piv) / world;
+        }
+        hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(256), 0, s,
+            R0, E, nb, ldp, dP, V, ws.Y, dYsum, 1, ws.acc, ws.scal);
+
+        // trailing updates on the owned blocks right of the panel (core.c:523-547)
+        for (int B = (i + nb) / cb; B * cb < E; B++) {
+            if (B % world != rank) continue;
+            int const c0 = std::max(B * cb, i + nb), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+            if (nt <= 0) continue;
+            double *At = dA + (size_t)c0 * ldA + R0;
+            dgemm(s, 'N', 'T', m, nt, nb, -1.0, ws.Y + R0, ldp, V + c0, ldp, 1.0, At, ldA);
+            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, ws.W, ldp);
+            dgemm(s, 'N', 'T', m, nt, nb, -1.0, V + R0, ldp, ws.W, ldp, 1.0, At, ldA);
+            gemm_flops += 6.0 * m * (double)nt * nb;
+        }
+        // every rank stores the finished panel columns (rows >= R0 are final)
+        hipLaunchKernelGGL(hess_copy_out_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
+            R0, E, nb, i, dA, ldA, dP, ldp);
+
+        // rows above the panel: W = sum over owned blocks A(0:R0, blk) VT(blk,:), all-reduce,
+        // A(0:R0, blk) -= W V(blk,:)^T   (core.c:321-327)
+        {
+            SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), s));
+            for (int B = R0 / cb; B * cb < E; B++) {
+                if (B % world != rank) continue;
+                int const c0 = std::max(B * cb, R0), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+                if (nt <= 0) continue;
+                dgemm(s, 'N', 'N', R0, nb, nt, 1.0, dA + (size_t)c0 * ldA, ldA, VT + c0, ldp, 1.0, dW2, R0);
+                gemm_flops += 2.0 * R0 * (double)nt * nb;
+            }
+            comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
+            for (int B = R0 / cb; B * cb < E; B++) {
+                if (B % world != rank) continue;
+                int const c0 = std::max(B * cb, R0), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+                if (nt <= 0) continue;
+                dgemm(s, 'N', 'T', R0, nt, nb, -1.0, dW2, R0, V + c0, ldp, 1.0, dA + (size_t)c0 * ldA, ldA);
+                gemm_flops += 2.0 * R0 * (double)nt * nb;
+            }
+        }
+        // Q: this rank's row block (core.c:339-340), no communication
+        if (dQ && q_hi > q_lo) {
+            int const rows = q_hi - q_lo;
+            double *X = dQ + (size_t)R0 * ldQ + q_lo;
+            dgemm(s, 'N', 'N', rows, nb, m, 1.0, X, ldQ, VT + R0, ldp, 0.0, ws.W2, ldp);
+            dgemm(s, 'N', 'T', rows, m, nb, -1.0, ws.W2, ldp, V + R0, ldp, 1.0, X, ldQ);
+            gemm_flops += 4.0 * rows * (double)m * nb;
+        }
+    }
+    // assemble H and Q on every rank
+    if (world > 1) {
+        hipLaunchKernelGGL(hess_zero_unowned_kernel, dim3(divceil(n, 256), std::min(n, 1024)), dim3(256), 0, s,
+            0, n, dA, ldA, cb, world, rank, 0, 0);
+        comm.allreduce_sum(comm.ctx, 3, 0, (long)ldA * n);
+        if (dQ) {
+            hipLaunchKernelGGL(hess_zero_unowned_kernel, dim3(divceil(n, 256), std::min(n, 1024)), dim3(256), 0, s,
+                1, n, dQ, ldQ, cb, world, rank, q_lo, q_hi);
+            comm.allreduce_sum(comm.ctx, 4, 0, (long)ldQ * n);
+        }
+    }
+    if (tm) {
+        SN_HIP_CHECK(hipEventRecord(ws.ev1, s));
+        SN_HIP_CHECK(hipEventSynchronize(ws.ev1));
+        float ms = 0.f;
+        SN_HIP_CHECK(hipEventElapsedTime(&ms, ws.ev0, ws.ev1));
+        tm->total_ms = ms;
+        tm->gemv_bytes = gemv_bytes;
+        tm->gemm_flops = gemm_flops;
+        tm->gemv_launches = gemv_launches;
     }
     return 0;
 }

@@ -1,0 +1,102 @@
+"""Multi-GPU driver of the sharded Hessenberg reduction: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI) provides the collectives.
+
+The C library does all the compute and calls back into this module for the two collectives
+it needs (all-reduce-sum, broadcast) on buffers that this module allocated; torch is
+plumbing only (device memory, the stream, the process group).
+
+Communication per reduction of an n x n matrix with panel width nb:
+  per panel : broadcast of the owner's panel columns  (ld*nb doubles)
+              all-reduce of W = A(0:i+1, .) V T        ((i+1)*nb doubles)
+  per column: all-reduce of the partial y = A v        (<= n doubles)
+  at the end: assembly of A and Q                      (2 * ld*n doubles)
+"""
+import ctypes as C
+import os
+import sys
+
+from . import lib
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_long, C.c_long)
+BROADCAST_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_int)
+
+
+def owned_column_blocks(n, block, world, rank):
+    """Column blocks (first, last_exclusive) of an n-column matrix owned by `rank`:
+    block b = c // block belongs to rank b % world (the rule of hessenberg_sharded_device)."""
+    return [(b * block, min(n, (b + 1) * block))
+            for b in range((n + block - 1) // block) if b % world == rank]
+
+
+def owned_q_rows(n, world, rank):
+    """Contiguous row block of Q owned by `rank` (multiples of 128 rows)."""
+    chunk = ((n + world - 1) // world + 127) // 128 * 128
+    return min(n, rank * chunk), min(n, (rank + 1) * chunk)
+
+
+class Collectives:
+    """Maps the library's (buffer id, offset, count) requests onto torch.distributed calls."""
+
+    def __init__(self, buffers, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.buffers = buffers          # id -> flat 1-D tensor
+        self.calls = {"allreduce": 0, "broadcast": 0, "bytes": 0}
+        self.allreduce_cb = ALLREDUCE_FN(self._allreduce)
+        self.broadcast_cb = BROADCAST_FN(self._broadcast)
+
+    def _global_rank(self, group_rank):
+        if self.group is None:
+            return group_rank
+        return self.dist.get_global_rank(self.group, group_rank)
+
+    def _allreduce(self, ctx, buf, off, cnt):
+        try:
+            t = self.buffers[buf][off:off + cnt]
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.calls["allreduce"] += 1
+            self.calls["bytes"] += 8 * cnt
+        except BaseException as e:      # an exception must not unwind through C: a rank that
+            sys.stderr.write(f"[starneig-amd] collective failed: {e!r}\n")   # drops out would
+            sys.stderr.flush()                                               # hang the others
+            os._exit(3)
+
+    def _broadcast(self, ctx, buf, off, cnt, root):
+        try:
+            t = self.buffers[buf][off:off + cnt]
+            self.dist.broadcast(t, src=self._global_rank(root), group=self.group)
+            self.calls["broadcast"] += 1
+            self.calls["bytes"] += 8 * cnt
+        except BaseException as e:
+            sys.stderr.write(f"[starneig-amd] collective failed: {e!r}\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+
+def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
+    """Reduces the matrix held (identically) by every rank in tA; on return every rank holds
+    the full Hessenberg form in tA and the full Q in tQ.  Returns (rc, stats)."""
+    import torch
+    import torch.distributed as dist
+    L = lib.load()
+    n = tA.shape[0] if n is None else n
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    pw = panel_width if panel_width > 0 else L.starneig_amd_default_panel_width(n)
+    ld = L.starneig_amd_hessenberg_panel_ld(n, pw)
+    dev = tA.device
+    tY = torch.zeros(ld, dtype=torch.float64, device=dev)
+    tP = torch.zeros(ld * pw, dtype=torch.float64, device=dev)
+    tW = torch.zeros(n * pw, dtype=torch.float64, device=dev)
+    coll = Collectives({0: tY, 1: tP, 2: tW, 3: tA.view(-1),
+                        4: tQ.view(-1) if tQ is not None else None}, group)
+    st = (C.c_double * 8)()
+    rc = L.starneig_amd_hessenberg_sharded_device(
+        n, pw, tA.data_ptr(), tA.shape[1], tQ.data_ptr() if tQ is not None else None,
+        tQ.shape[1] if tQ is not None else 0, tY.data_ptr(), tP.data_ptr(), tW.data_ptr(),
+        tW.numel(), rank, world,
+        C.cast(coll.allreduce_cb, C.c_void_p), C.cast(coll.broadcast_cb, C.c_void_p),
+        None, torch.cuda.current_stream().cuda_stream, st)
+    stats = {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
+             "gemv_launches": int(st[5]), "collectives": dict(coll.calls)}
+    return rc, stats

@@ -70,6 +70,10 @@ SIGNATURES = {
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
         C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
+    "starneig_amd_hessenberg_panel_ld": (C.c_int, [C.c_int, C.c_int]),
+    "starneig_amd_hessenberg_sharded_device": (
+        C.c_int, [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_long,
+                  C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp]),
     "starneig_amd_dgemm_device": (
         C.c_int, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int,
                   _vp, C.c_int, C.c_double, _vp, C.c_int, _vp]),

@@ -1,0 +1,20 @@
+"""GPU: the N > 1 (sharded) Hessenberg path with 2 and 3 processes sharing cuda:0 over gloo."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,n,pw", [(2, 700, 64), (3, 1000, 96), (2, 333, 40)])
+def test_sharded_hessenberg_matches_single_gpu(world, n, pw):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + world * 7 + n % 97),
+           os.path.join(ROOT, "tests", "dist_hess_worker.py"), str(n), str(pw)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "DIST-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
