@@ -8,8 +8,10 @@ synthetic n x n matrix (the reference test driver's LCG input, seed 2019, genera
 directly in HBM; Q = I), inputs resident in HBM when the timed region starts.
 Prints ONE JSON line (rank 0).
 
-At N > 1 every rank reduces its own matrix on its own GPU (replicas, weak scaling):
-the block-column sharding of SURVEY.md section 8(e) is not built yet.
+At N > 1 the N GPUs reduce ONE matrix together (strong scaling): the Hessenberg leg is
+sharded by block column (per-column all-reduce of the partial y = A v, panel broadcast,
+starneig_amd/distributed.py); the Schur leg is not sharded yet -- every rank runs it on
+its full copy -- so N > 1 only shortens the Hessenberg part.
 """
 import argparse
 import json
@@ -72,8 +74,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--size", "--n", dest="n", type=int, default=20000)
     ap.add_argument("--cpu-n", type=int, default=1500, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the sharded Hessenberg path even at N=1 (exercises the collectives)")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
@@ -84,8 +88,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -97,13 +104,13 @@ def main():
 
     n = args.n
     tA0 = S.device_matrix(n)
-    assert S.lcg_fill_device(tA0, n, n, seed=2019 + rank, mode=0) == 0
+    assert S.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0       # the same matrix on every rank
     tA = torch.empty_like(tA0)
     tQ = S.device_matrix(n)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -112,7 +119,12 @@ def main():
         S.set_matrix_device(tQ, n, n, 0.0, 1.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=sample_every)
+        if sharded:
+            from starneig_amd import distributed as D
+            rc, st = D.hessenberg_sharded(tA, tQ, n=n)
+            st.update({"gemv_sampled_ms": 0.0, "gemv_sampled_bytes": 0.0, "gemv_sampled_launches": 0})
+        else:
+            rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=sample_every)
         torch.cuda.synchronize()
         assert rc == 0
         t1 = time.perf_counter()
@@ -137,7 +149,7 @@ def main():
     barrier()
     total = sum(step_s)         # input reset (copy + identity) is outside the timed region
     t = torch.tensor([total], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if sharded:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     total = t.item()
 
@@ -147,7 +159,7 @@ def main():
 
     if rank == 0:
         ms_per_step = total / args.steps * 1e3
-        value = world * args.steps * (hess_flops(n) + schur_flops(n)) / total / 1e9
+        value = args.steps * (hess_flops(n) + schur_flops(n)) / total / 1e9   # ONE job on all GPUs
         sm = sum(s["gemv_sampled_ms"] for s in stats)
         sb = sum(s["gemv_sampled_bytes"] for s in stats)
         nl = sum(s["gemv_sampled_launches"] for s in stats)
@@ -157,12 +169,15 @@ def main():
             "metric": "GFLOP/s Hessenberg+Schur, n=20000 real dense, 1/2/4/8 MI355X; residual",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"Hessenberg + multi-shift QR Schur, n={n}, Q accumulated, LCG input "
                             f"seed 2019 (BASELINE config 3); value = (16/3 + 25) n^3 flop / time",
                 "n": n, "panel_width": S.default_panel_width(n),
-                "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+                "parallelism": "single GPU" if not sharded else
+                               f"Hessenberg sharded by block column over {world} GPU(s) (RCCL: per-column "
+                               f"all-reduce of y, panel broadcast); Schur replicated on every rank",
+                "collectives": stats[-1].get("collectives"),
                 "residual_u": chk["residual_u"], "orthogonality_u": chk["orthogonality_u"],
                 "below_subdiagonal_nonzeros": chk["below_subdiagonal"],
                 "hessenberg_s": stats[-1]["hessenberg_s"], "schur_s": stats[-1]["schur_s"],
@@ -189,7 +204,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     S.node_finalize()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
