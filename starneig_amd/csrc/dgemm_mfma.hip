@@ -30,8 +30,20 @@ void dgemm_kernel(int m, int n, int k, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
     double beta, double *__restrict__ C, int ldc, int tiles_m)
 {
-    gemm_tile<BM, BN, KT, TA, TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc,
-        blockIdx.x % tiles_m, blockIdx.x / tiles_m);
+    // Tile order (speed only): blocks are dealt round-robin over the 8 XCDs, so give every
+    // XCD a contiguous range of tile ids (its private L2 then sees neighbouring tiles), and
+    // walk the tiles in groups of 8 tile-rows so that the ~64 tiles resident on one XCD
+    // cover an 8 x 8 patch: 16 operand panels instead of 65.
+    int const nwg = gridDim.x, tiles_n = nwg / tiles_m;
+    int pid = blockIdx.x;
+    int const cpx = nwg / 8;
+    if (pid < cpx * 8) pid = (pid % 8) * cpx + pid / 8;
+    constexpr int GROUP_M = 8;
+    int const in_group = GROUP_M * tiles_n;
+    int const group = pid / in_group, first_m = group * GROUP_M;
+    int const gsize = min(tiles_m - first_m, GROUP_M);
+    int const bm = first_m + (pid % in_group) % gsize, bn = (pid % in_group) / gsize;
+    gemm_tile<BM, BN, KT, TA, TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn);
 }
 
 // Batched form: blockIdx.y selects a problem descriptor (alpha = 1, beta = 0).  Used for the
