@@ -135,3 +135,16 @@ def test_full_chain_reduce_config1(node):
     # trace and the dominant (Perron) eigenvalue of the positive matrix are preserved
     assert abs(real.sum() - np.trace(A0[:n])) <= 1e-10 * abs(np.trace(A0[:n]))
     assert abs(real.max() - np.abs(np.linalg.eigvals(A0[:n])).max()) <= 1e-10 * n
+
+
+@pytest.mark.parametrize("n", [64, 200, 512])
+def test_eigenvalues_match_lapack_golden(node, n):
+    """committed numpy/LAPACK eigenvalues of the LCG matrices (tests/golden)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"hessenberg_lcg2019_n{n}.npz"))
+    A0 = O.random_fullpos(n, seed=int(g["seed"]))
+    A = A0.copy(order="F"); Q = O.identity(n)
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Reduce(n, A, A.shape[0], Q, Q.shape[0], real, imag) == 0
+    assert O.match_eigenvalues(real + 1j * imag, g["eig_real"] + 1j * g["eig_imag"]) < 1e4
+    assert O.check_schur_form(A) == 0 and O.residual_u(Q, A, A0) < WARN_U

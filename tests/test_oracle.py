@@ -100,3 +100,42 @@ def test_dlarfg_known_answers():
 def test_default_panel_width():
     # hessenberg/interface.c:74-78: 280 @ 2000, 288 @ 4000/8000, 312 @ 20000
     assert [O.default_panel_width(n) for n in (2000, 4000, 8000, 20000)] == [280, 288, 288, 312]
+
+
+@pytest.mark.parametrize("n", [64, 200, 512])
+def test_schur_oracle_matches_lapack_golden_eigenvalues(n):
+    """Schur leg of the oracle (double-shift QR restatement) against numpy/LAPACK eigenvalues of
+    the same LCG matrix (fixture), plus the reference's Schur-form / residual checks."""
+    g = np.load(os.path.join(GOLDEN, f"hessenberg_lcg2019_n{n}.npz"))
+    A0 = O.random_fullpos(n, seed=int(g["seed"]))
+    H = A0.copy(order="F"); Q = O.identity(n)
+    O.hessenberg(H, Q)
+    wr, wi = O.schur(H, Q)
+    assert O.check_schur_form(H) == 0
+    assert O.residual_u(Q, H, A0) < WARN_U
+    assert O.orthogonality_u(Q) < WARN_U
+    ev = g["eig_real"] + 1j * g["eig_imag"]
+    assert O.match_eigenvalues(wr + 1j * wi, ev) < 1e4          # reference warn level
+    er, ei = O.extract_eigenvalues(H)
+    assert np.array_equal(er, wr) and np.array_equal(ei, wi)
+
+
+def test_dlanv2_known_answers():
+    """LAPACK dlanv2 semantics on hand-checked blocks."""
+    import ctypes as C
+    L = O.lib()
+    L.oracle_dlanv2.argtypes = [C.POINTER(C.c_double)] * 10
+    def run(a, b, c, d):
+        v = [C.c_double(x) for x in (a, b, c, d)] + [C.c_double() for _ in range(6)]
+        L.oracle_dlanv2(*[C.byref(x) for x in v])
+        return [x.value for x in v]
+    # already upper triangular
+    a, b, c, d, r1, i1, r2, i2, cs, sn = run(1.0, 2.0, 0.0, 3.0)
+    assert (a, b, c, d, r1, i1, r2, i2, cs, sn) == (1.0, 2.0, 0.0, 3.0, 1.0, 0.0, 3.0, 0.0, 1.0, 0.0)
+    # complex pair: rotation matrix scaled -> standard form keeps equal diagonal, b*c < 0
+    a, b, c, d, r1, i1, r2, i2, cs, sn = run(1.0, -2.0, 2.0, 1.0)
+    assert a == d == 1.0 and b * c < 0 and (r1, r2) == (1.0, 1.0) and abs(i1 - 2.0) < 1e-15 and i2 == -i1
+    # real eigenvalues 1 and 4 of [[2,1],[2,3]]: c is annihilated
+    a, b, c, d, r1, i1, r2, i2, cs, sn = run(2.0, 1.0, 2.0, 3.0)
+    assert c == 0.0 and i1 == 0.0 and sorted([round(r1, 12), round(r2, 12)]) == [1.0, 4.0]
+    assert abs(cs * cs + sn * sn - 1.0) < 1e-15
