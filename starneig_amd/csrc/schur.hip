@@ -201,8 +201,13 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     }
 }
 
-// Off-diagonal updates of all chains of one step (row S3): MODE 0: H(win, right of win) <-
-// U^T ., MODE 1: H(above win, win) <- . U and (blockIdx.y >= ntasks) Q(:, win) <- . U.
+// Off-diagonal updates of all chains of one step (row S3).
+//   MODE 2 ("near"): H(win, next `adv` columns right of win) <- U^T .  -- the only part of the
+//                    updates the chain's NEXT window needs; stays on the critical stream.
+//   MODE 0 ("far") : the remaining columns right of the window.
+//   MODE 1         : H(above win, win) <- . U and (blockIdx.y >= ntasks) Q(:, win) <- . U.
+// MODE 0/1 run on a second stream concurrently with the next chase launch (chains are
+// spaced ws+adv rows apart so that no other chain's next window touches them).
 // One workgroup owns all w <= 128 rows (columns) of its tile and reads its whole operand
 // panel before the epilogue writes, so the update is done in place.
 template <int MODE>
@@ -215,10 +220,12 @@ void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     ChaseTask const t = make_task(step, k);
     double const *Uk = U + (size_t)k * WS_MAX * WS_MAX;
     int const w = t.n, lo = t.lo;
-    if (MODE == 0) {
-        int const ncols = n - (lo + w);
+    if (MODE == 0 || MODE == 2) {
+        int const c0 = (MODE == 2) ? lo + w : lo + w + step.adv;
+        int ncols = n - c0;
+        if (MODE == 2) ncols = min(ncols, step.adv);
         if ((int)blockIdx.x * 128 >= ncols) return;
-        double *X = H + (size_t)(lo + w) * ldH + lo;
+        double *X = H + (size_t)c0 * ldH + lo;
         gemm_tile<128, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH,
             0, blockIdx.x);
     } else {
@@ -277,6 +284,9 @@ struct SchurWorkspace {
     double *hWin = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
     ChaseTask *hTasks = nullptr;
     bool attr_set = false;
+    hipStream_t far = nullptr;
+    static constexpr int EV_RING = 64;
+    hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
 
     void release() {
         void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dDescs, (void **)&dShiftR, (void **)&dShiftI,
@@ -290,7 +300,7 @@ struct SchurWorkspace {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
-        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)max_chains * WS_MAX * WS_MAX * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * WS_MAX * WS_MAX * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
@@ -304,6 +314,13 @@ struct SchurWorkspace {
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+            SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
+            for (int k = 0; k < EV_RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&far_done[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<2>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<0>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<1>,
@@ -419,7 +436,8 @@ struct Driver {
         nbc = std::min(nbc, NB_MAX);
         int const chains = divceil(nbulges, nbc);
         int const adv = ws_ - 1 - 3 * nbc;                    // columns a chain advances per step
-        int const gap = (adv > 0) ? divceil(ws_, adv) : 1;    // steps between chain starts
+        // chains ws+adv rows apart: a chain's next window then depends on its OWN near update only
+        int const gap = (adv > 0) ? divceil(ws_ + adv, adv) : 1;
         SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftR, sr, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
         SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftI, si, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
 
@@ -430,6 +448,13 @@ struct Driver {
         else steps_per_chain = divceil(size - ws_, adv) + 1;
         int const total_steps = steps_per_chain + (chains - 1) * gap;
         SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
+        // Pipeline: critical stream s:  chase(t) -> [wait far(t-1)] near(t)
+        //           far stream       :  [wait near(t)] far-left(t), right/Q(t)
+        // so chase(t+1) overlaps far(t).  U is double-buffered by step parity; chase(t+2)
+        // follows near(t+1) which waited for far(t), the last reader of its U buffer.
+        hipStream_t const f = ws.far;
+        long issued = 0;
+        int last_t = -2;
         for (int t = 0; t < total_steps; t++) {
             int cmin = (t - steps_per_chain + 1 + gap - 1) / gap;      // ceil for positives
             if (t - steps_per_chain + 1 <= 0) cmin = 0;
@@ -437,31 +462,63 @@ struct Driver {
             if (cmax < cmin) continue;
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
+            int const par = (int)(issued & 1);
+            double *Ubuf = ws.dU + (size_t)par * ws.max_chains * WS_MAX * WS_MAX;
+            int const ev = (int)(issued % SchurWorkspace::EV_RING);
+            int const evp = (int)((issued + SchurWorkspace::EV_RING - 1) % SchurWorkspace::EV_RING);
+            // chase(t) may overlap far(t-1) only in the regular regime.  On short active blocks
+            // steps are skipped (a chain finishes before the next one is introduced) and the new
+            // chain's first window would race with the finished chain's pending updates
+            // (tests/test_schur_pipeline.py checks this rule on a model of the schedule).
+            if (issued > 0 && last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
-                step, H, ldH, ws.dU, ws.dShiftR, ws.dShiftI);
+                step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
-            int max_cols = 0;
+            int max_far = 0;
             for (int k = 0; k < ntasks; k++) {
                 ChaseTask const tk = make_task(step, k);
                 int const rc = n - (tk.lo + tk.n);
-                max_cols = std::max(max_cols, rc);
+                max_far = std::max(max_far, rc - adv);
                 st.gemm_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
             }
-            if (max_cols > 0)
-                hipLaunchKernelGGL(schur_update_kernel<0>, dim3(divceil(max_cols, 128), ntasks), dim3(256),
-                    UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, ws.dU);
+            if (issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            hipLaunchKernelGGL(schur_update_kernel<2>, dim3(1, ntasks), dim3(256),
+                UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, Ubuf);
+            SN_HIP_CHECK(hipEventRecord(ws.near_done[ev], s));
+            SN_HIP_CHECK(hipStreamWaitEvent(f, ws.near_done[ev], 0));
+            if (max_far > 0)
+                hipLaunchKernelGGL(schur_update_kernel<0>, dim3(divceil(max_far, 128), ntasks), dim3(256),
+                    UPDATE_LDS_BYTES_L, f, step, H, ldH, Q, ldQ, n, Ubuf);
             hipLaunchKernelGGL(schur_update_kernel<1>, dim3(divceil(n, 128), Q ? 2 * ntasks : ntasks),
-                dim3(256), UPDATE_LDS_BYTES_R, s, step, H, ldH, Q, ldQ, n, ws.dU);
+                dim3(256), UPDATE_LDS_BYTES_R, f, step, H, ldH, Q, ldQ, n, Ubuf);
+            SN_HIP_CHECK(hipEventRecord(ws.far_done[ev], f));
+            issued++;
+            last_t = t;
         }
+        // the sweep is complete when the far stream has drained
+        if (issued > 0)
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((issued - 1) % SchurWorkspace::EV_RING)], 0));
         st.sweeps++;
     }
 };
 
 } // namespace
 
-int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
+int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int ldQ,
     double *real, double *imag, SchurParams const &prm, SchurStats *stats)
 {
+    // the whole reduction runs on the library's own stream pair (never on the legacy NULL
+    // stream), fenced against the caller's stream at entry and exit
+    static hipStream_t own = nullptr;
+    static hipEvent_t fence = nullptr;
+    if (!own) {
+        SN_HIP_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+        SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
+    }
+    hipStream_t s = own;
+    SN_HIP_CHECK(hipEventRecord(fence, caller));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, fence, 0));
+
     // ---- parameters (schur/process_args.c:116-162, :271-288, :356) --------------------------
     int const min_val = lapack_min_shifts(n);
     int nw_default = (int)std::max(min_val / 0.7, 0.08 * n);
@@ -575,6 +632,7 @@ int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
         iter++;
     }
     SN_HIP_CHECK(hipEventRecord(e1, s));
+    SN_HIP_CHECK(hipStreamWaitEvent(caller, e1, 0));
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
