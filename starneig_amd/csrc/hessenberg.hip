@@ -570,7 +570,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         SN_HIP_CHECK(hipEventRecord(ws.panel_done[buf], s));
 
         // ---- non-critical updates on the side stream (core.c:321-340) ----
-        hipStream_t q = ws.side;
+        hipStream_t q = getenv("SN_HESS_NOSIDE") ? s : ws.side;
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)
             double *X = dA + (size_t)R0 * ldA;
