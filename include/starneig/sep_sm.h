@@ -38,6 +38,15 @@ starneig_error_t starneig_SEP_SM_Schur_expert(
     struct starneig_schur_conf *conf, int n, double H[], int ldH,
     double Q[], int ldQ, double real[], double imag[]);
 
+/* Evaluates `predicate` on every eigenvalue of the Schur form S (host array); both members
+ * of a complex pair get the same flag, a selected pair counts twice (reference
+ * sep_sm.h:327-334, common/helpers.c:47-101).  Errors: n<1 -> -1, S NULL -> -2, ldS<n -> -3,
+ * predicate NULL -> -4, selected NULL -> -6. */
+starneig_error_t starneig_SEP_SM_Select(
+    int n, double S[], int ldS,
+    int (*predicate)(double real, double imag, void *arg), void *arg,
+    int selected[], int *num_selected);
+
 /* Hessenberg followed by Schur (the reordering leg of common/combined.c:46-98
  * is outside this path: predicate must be NULL). */
 starneig_error_t starneig_SEP_SM_Reduce(

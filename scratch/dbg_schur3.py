@@ -11,9 +11,11 @@ rc, hst = S.hessenberg_device(tH, tQ0, n=n, stats=True)
 torch.cuda.synchronize()
 print("hess %.2fs" % (hst["total_ms"]/1e3), flush=True)
 for cfg in sys.argv[2:]:
-    aed, ns, small = [int(x) for x in cfg.split(",")]
+    parts = [int(x) for x in cfg.split(",")]
+    aed, ns, small = parts[:3]
+    nib = parts[3] if len(parts) > 3 else -1
     tA = tH.clone(); tQ = tQ0.clone()
-    conf = S.schur_init_conf(); conf.aed_window_size=aed; conf.shift_count=ns; conf.small_limit=small
+    conf = S.schur_init_conf(); conf.aed_window_size=aed; conf.shift_count=ns; conf.small_limit=small; conf.aed_nibble=nib
     t=time.time()
     rc, real, imag, st = S.schur_device(tA, tQ, n=n, conf=conf)
     torch.cuda.synchronize(); dt=time.time()-t

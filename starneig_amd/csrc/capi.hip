@@ -3,6 +3,7 @@
 // extension (include/starneig_amd.h).  There is deliberately no CPU fallback:
 // without a usable gfx950 device starneig_node_init() aborts.
 #include "common.h"
+#include "schur_host.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -255,6 +256,36 @@ SN_API starneig_error_t starneig_SEP_SM_Schur(
     if (ldQ < n)    return -5;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     return starneig_SEP_SM_Schur_expert(NULL, n, H, ldH, Q, ldQ, real, imag);
+}
+
+// common/helpers.c:47-101: evaluate a predicate on the eigenvalues of a Schur form
+SN_API starneig_error_t starneig_SEP_SM_Select(
+    int n, double S[], int ldS,
+    int (*predicate)(double real, double imag, void *arg), void *arg,
+    int selected[], int *num_selected)
+{
+    if (n < 1)              return -1;
+    if (S == NULL)          return -2;
+    if (ldS < n)            return -3;
+    if (predicate == NULL)  return -4;
+    if (selected == NULL)   return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    std::vector<double> wr(n), wi(n);
+    sn::host::extract_eigenvalues(n, S, ldS, wr.data(), wi.data());
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        if (wi[i] != 0.0 && i + 1 < n) {            // a 2x2 block: both or none
+            int sel = predicate(wr[i], wi[i], arg) ? 1 : 0;
+            selected[i] = selected[i + 1] = sel;
+            count += 2 * sel;
+            i++;
+        } else {
+            selected[i] = predicate(wr[i], 0.0, arg) ? 1 : 0;
+            count += selected[i];
+        }
+    }
+    if (num_selected != NULL) *num_selected = count;
+    return STARNEIG_SUCCESS;
 }
 
 // common/combined.c:46-98 without the reordering leg (predicate must be NULL)

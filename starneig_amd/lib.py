@@ -66,6 +66,7 @@ SIGNATURES = {
         C.c_int, [C.POINTER(SchurConf), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "starneig_SEP_SM_Reduce": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "starneig_SEP_SM_Select": (C.c_int, [C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "starneig_amd_schur_device": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
@@ -174,6 +175,45 @@ def SEP_SM_Reduce(n, A, ldA, Q, ldQ, real, imag):
     return load().starneig_SEP_SM_Reduce(
         n, _host_ptr(A), ldA, _host_ptr(Q), ldQ, real.ctypes.data, imag.ctypes.data,
         None, None, None, None)
+
+
+PREDICATE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_void_p)
+
+
+def SEP_SM_Select(n, S, ldS, predicate):
+    """reference sep_sm.h:327-334; predicate(real, imag) -> bool.  Returns (rc, selected, count)."""
+    cb = PREDICATE_FN(lambda re, im, arg: 1 if predicate(re, im) else 0) if predicate else None
+    sel = np.zeros(n, dtype=np.int32)
+    cnt = C.c_int(0)
+    rc = load().starneig_SEP_SM_Select(
+        n, _host_ptr(S), ldS, C.cast(cb, C.c_void_p) if cb else None, None,
+        sel.ctypes.data, C.addressof(cnt))
+    return rc, sel, cnt.value
+
+
+RAW_HEADER = "STARNEIG RAW REAL DOUBLE M %d N %d\n"
+
+
+def write_raw(path, A):
+    """The reference test driver's raw matrix format (test/common/io.c:217-268): one header
+    line, then the columns as native doubles -- fixtures written here can be fed to
+    `starneig-test --init read-raw` and vice versa."""
+    A = np.asarray(A, dtype=np.float64)
+    with open(path, "wb") as f:
+        f.write((RAW_HEADER % A.shape).encode())
+        f.write(np.asfortranarray(A).tobytes(order="F"))
+
+
+def read_raw(path):
+    import re
+    with open(path, "rb") as f:
+        header = f.readline().decode()
+        m = re.match(r"STARNEIG RAW REAL DOUBLE M (\d+) N (\d+)", header)
+        if not m:
+            raise ValueError("not a STARNEIG RAW file")
+        rows, cols = int(m.group(1)), int(m.group(2))
+        data = np.frombuffer(f.read(rows * cols * 8), dtype=np.float64)
+    return np.asfortranarray(data.reshape((rows, cols), order="F"))
 
 
 # ---- device-pointer extension (torch tensors only carry the memory) ---------------

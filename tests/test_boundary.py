@@ -73,3 +73,25 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(root, f)).read()
                 assert "oracle" not in text.lower() or f == "lib.py" and False, (root, f)
+
+
+def test_select_argument_checks_and_raw_io(tmp_path):
+    """common/helpers.c:55-62 argument order; test/common/io.c raw format round trip."""
+    n = 4
+    Smat = np.asfortranarray(np.triu(np.arange(16, dtype=np.float64).reshape(4, 4)))
+    L = S.lib.load()
+    import ctypes as C
+    cb = S.lib.PREDICATE_FN(lambda re, im, arg: 1)
+    fn = C.cast(cb, C.c_void_p)
+    sel = np.zeros(n, dtype=np.int32)
+    assert L.starneig_SEP_SM_Select(0, Smat.ctypes.data, n, fn, None, sel.ctypes.data, None) == -1
+    assert L.starneig_SEP_SM_Select(n, None, n, fn, None, sel.ctypes.data, None) == -2
+    assert L.starneig_SEP_SM_Select(n, Smat.ctypes.data, n - 1, fn, None, sel.ctypes.data, None) == -3
+    assert L.starneig_SEP_SM_Select(n, Smat.ctypes.data, n, None, None, sel.ctypes.data, None) == -4
+    assert L.starneig_SEP_SM_Select(n, Smat.ctypes.data, n, fn, None, None, None) == -6
+    assert L.starneig_SEP_SM_Select(n, Smat.ctypes.data, n, fn, None, sel.ctypes.data, None) == S.NOT_INITIALIZED
+    A = np.asfortranarray(np.random.RandomState(0).rand(5, 3))
+    path = tmp_path / "a.raw"
+    S.lib.write_raw(str(path), A)
+    assert open(path, "rb").readline() == b"STARNEIG RAW REAL DOUBLE M 5 N 3\n"
+    assert np.array_equal(S.lib.read_raw(str(path)), A)

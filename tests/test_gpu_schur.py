@@ -148,3 +148,17 @@ def test_eigenvalues_match_lapack_golden(node, n):
     assert node.SEP_SM_Reduce(n, A, A.shape[0], Q, Q.shape[0], real, imag) == 0
     assert O.match_eigenvalues(real + 1j * imag, g["eig_real"] + 1j * g["eig_imag"]) < 1e4
     assert O.check_schur_form(A) == 0 and O.residual_u(Q, A, A0) < WARN_U
+
+
+def test_select_on_schur_form(node):
+    """starneig_SEP_SM_Select (common/helpers.c:47-101): pairs are selected together."""
+    n = 200
+    A0, H0, Q0 = hessenberg_of_lcg(n)
+    H = H0.copy(order="F"); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
+    rc, sel, cnt = node.SEP_SM_Select(n, H, H.shape[0], lambda re, im: re > 0.0)
+    assert rc == 0 and cnt == int((real > 0).sum()) and np.array_equal(sel.astype(bool), real > 0)
+    for i in range(n - 1):
+        if imag[i] > 0:
+            assert sel[i] == sel[i + 1]
