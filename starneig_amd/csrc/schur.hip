@@ -625,7 +625,28 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         if (100 * ar.deflated > nibble * nw) continue;
         int nshifts = std::min(ar.shifts, ns_conf);
         nshifts -= nshifts % 2;
-        if (nshifts < 2) { stagnation++; if (stagnation > 10) { rc = STARNEIG_DID_NOT_CONVERGE; break; } continue; }
+        // Exceptional shifts (the LAPACK dlaqr0 recipe, every 6th sweep without deflation, or
+        // when the window offers no usable shift -- e.g. a nilpotent trailing block): pairs
+        // from [0.75 s + h_ii, s; -0.4375 s, 0.75 s + h_ii], s = |h_{i,i-1}| + |h_{i-1,i-2}|.
+        if (nshifts < 2 || (stagnation > 0 && stagnation % 6 == 0)) {
+            int const want = std::max(2, std::min(ns_conf, (ihi - ilo - 2) / 2 * 2));
+            std::vector<double> dg(want + 2);
+            int const first = ihi - (want + 2) >= 0 ? ihi - (want + 2) : 0;
+            int const cnt = ihi - first;
+            SN_HIP_CHECK(hipMemcpy2DAsync(dg.data(), 8, dH + (size_t)first * ldH + first, (size_t)(ldH + 1) * 8,
+                8, cnt, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            nshifts = 0;
+            for (int i = ihi - 1; i >= ilo + 2 && nshifts + 2 <= want; i -= 2) {
+                double ss = std::fabs(ws.hSub[i - 1]) + std::fabs(ws.hSub[i - 2]);
+                double aa = 0.75 * ss + dg[i - first], bb = ss, cc = -0.4375 * ss, dd = aa, cs, sn;
+                host::lanv2(aa, bb, cc, dd, sr[nshifts], si[nshifts], sr[nshifts + 1], si[nshifts + 1], cs, sn);
+                if (ss == 0.0) { sr[nshifts] = sr[nshifts + 1] = dg[i - first] + 1e-3 * (1.0 + std::fabs(dg[i - first])); si[nshifts] = si[nshifts + 1] = 0.0; }
+                nshifts += 2;
+            }
+            if (nshifts < 2) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+        }
+        if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
         // ---- multi-shift sweep -----------------------------------------------------------------------
         d.sweep(ilo, ihi, nshifts, sr.data(), si.data());

@@ -162,3 +162,41 @@ def test_select_on_schur_form(node):
     for i in range(n - 1):
         if imag[i] > 0:
             assert sel[i] == sel[i + 1]
+
+
+def _special_matrices(n):
+    import scipy.linalg as sl
+    rng = np.random.RandomState(0)
+    comp = np.eye(n, k=-1); comp[0, n - 1] = 1.0
+    comp2 = np.eye(n, k=-1); comp2[0, :] = rng.randn(n) * 1e-3
+    return {
+        "orthogonal": sl.hessenberg(sl.qr(rng.randn(n, n))[0]),
+        "companion_unit_circle": comp,            # needs exceptional shifts (zero trailing block)
+        "companion_random": comp2,
+        "toeplitz_tridiagonal": 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1),
+        "jordan_like": 3 * np.eye(n) + np.eye(n, k=1) + 1e-8 * np.eye(n, k=-1),
+        "graded": sl.hessenberg(rng.randn(n, n) * np.logspace(0, -15, n)[:, None]),
+        "symmetric": sl.hessenberg((lambda M: M + M.T)(rng.randn(n, n))),
+        "all_ones": np.triu(np.ones((n, n)), -1),
+        "zero": np.zeros((n, n)),
+        "scaled_1e150": sl.hessenberg(rng.randn(n, n)) * 1e150,
+        "scaled_1e-150": sl.hessenberg(rng.randn(n, n)) * 1e-150,
+    }
+
+
+@pytest.mark.parametrize("name", ["orthogonal", "companion_unit_circle", "companion_random",
+                                  "toeplitz_tridiagonal", "jordan_like", "graded", "symmetric",
+                                  "all_ones", "zero", "scaled_1e150", "scaled_1e-150"])
+def test_special_matrices_converge(node, name):
+    """hard inputs for QR iterations: equal-modulus spectra, defective and graded matrices,
+    extreme scaling (the chase kernel's scaled reflectors, exceptional shifts)"""
+    n = 400
+    H0 = np.asfortranarray(_special_matrices(n)[name])
+    H = H0.copy(order="F"); Q = np.asfortranarray(np.eye(n))
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H, n, Q, n, real, imag) == 0
+    assert O.check_schur_form(H) == 0
+    nrm = np.linalg.norm(H0)
+    if nrm > 0:
+        assert np.linalg.norm(Q @ H @ Q.T - H0) / nrm < WARN_U * U
+    assert np.linalg.norm(Q @ Q.T - np.eye(n)) / np.sqrt(n) < WARN_U * U
