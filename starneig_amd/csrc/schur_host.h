@@ -18,4 +18,14 @@ int extract_shifts(int n, const double *T, int ldt, double *wr, double *wi);
 AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     double thres, double *spike, double *sr, double *si);
 
+// ---- generalized problem (schur_host_gep.hip) ---------------------------------------------
+void gep_extract_eigenvalues(int n, const double *S, int lds, const double *T, int ldt,
+    double *ar, double *ai, double *be);
+int gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int nq, double *ar, double *ai, double *be);
+void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,
+    double *Q, int ldq, double *Z, int ldz, int nq);
+AedResult gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si);
+
 }} // namespace sn::host

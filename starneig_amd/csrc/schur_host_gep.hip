@@ -1,0 +1,408 @@
+// Host-side sequential kernels of the GENERALIZED Schur path (QZ, row S9 of SURVEY.md 8a):
+// small Hessenberg-triangular pencils that sit on the critical path of the multi-shift QZ
+// iteration -- the AED window and the final small blocks.
+//
+// The reference runs these on a CPU worker through LAPACK (dhgeqz for pencils <= 64 rows,
+// its own sequential QZ loop above that, dgghrd, dtgexc, dlagv2, dlag2:
+// schur/cpu_utils.c:2248-2309, :2651-2716, :3185-3371, common/math.c:148-176).  No LAPACK
+// here: the published algorithms (Moler & Stewart's QZ step as in Golub & Van Loan
+// Alg. 7.7.2, the dgghrd Givens scheme) are written out for windows of a few hundred rows.
+// Differences to LAPACK's dhgeqz: always the implicit double-shift step (real shift pairs
+// included); a (numerically) zero diagonal entry of B inside an active block is perturbed to
+// u*||B||_F instead of being chased out as an infinite eigenvalue (a backward error of the
+// same size as rounding; the reference's push_inf_* machinery, cpu_utils.c:360-799, is not
+// rebuilt); the AED deflates the trailing run of converged eigenvalues without reordering
+// (no dtgexc).
+#include "schur_host.h"
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace sn { namespace host {
+
+namespace {
+
+inline double sgn(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::fabs(a); }
+
+// Givens: [c s; -s c] [f; g] = [r; 0]
+inline void givens(double f, double g, double &c, double &s, double &r)
+{
+    if (g == 0.0) { c = 1.0; s = 0.0; r = f; return; }
+    if (f == 0.0) { c = 0.0; s = 1.0; r = g; return; }
+    r = std::hypot(f, g); c = f / r; s = g / r;
+}
+
+struct Mat { double *p; int ld; inline double &operator()(int i, int j) const { return p[(size_t)j * ld + i]; } };
+
+// rows r1,r2 over columns [c0,c1): x' = c x + s y, y' = c y - s x
+inline void rot_rows(Mat M, int r1, int r2, int c0, int c1, double c, double s)
+{
+    for (int j = c0; j < c1; j++) { double x = M(r1, j), y = M(r2, j); M(r1, j) = c * x + s * y; M(r2, j) = c * y - s * x; }
+}
+inline void rot_cols(Mat M, int c1_, int c2_, int r0, int r1, double c, double s)
+{
+    double *a = &M(0, c1_), *b = &M(0, c2_);
+    for (int i = r0; i < r1; i++) { double x = a[i], y = b[i]; a[i] = c * x + s * y; b[i] = c * y - s * x; }
+}
+
+// Householder with the pivot FIRST: (I - tau v v^T) x = beta e_1, v[0] = 1
+inline double house_first(int n, const double *x, double *v, double &beta)
+{
+    double xn = 0.0;
+    for (int i = 1; i < n; i++) xn = std::hypot(xn, x[i]);
+    v[0] = 1.0;
+    if (xn == 0.0) { for (int i = 1; i < n; i++) v[i] = 0.0; beta = x[0]; return 0.0; }
+    beta = -sgn(std::hypot(x[0], xn), x[0]);
+    double sc = 1.0 / (x[0] - beta);
+    for (int i = 1; i < n; i++) v[i] = x[i] * sc;
+    return (beta - x[0]) / beta;
+}
+// Householder with the pivot LAST: x^T (I - tau v v^T) = beta e_n^T, v[n-1] = 1
+inline double house_last(int n, const double *x, double *v, double &beta)
+{
+    double xn = 0.0;
+    for (int i = 0; i + 1 < n; i++) xn = std::hypot(xn, x[i]);
+    v[n - 1] = 1.0;
+    if (xn == 0.0) { for (int i = 0; i + 1 < n; i++) v[i] = 0.0; beta = x[n - 1]; return 0.0; }
+    beta = -sgn(std::hypot(x[n - 1], xn), x[n - 1]);
+    double sc = 1.0 / (x[n - 1] - beta);
+    for (int i = 0; i + 1 < n; i++) v[i] = x[i] * sc;
+    return (beta - x[n - 1]) / beta;
+}
+// M(r0:r0+len, c0:c1) <- (I - tau v v^T) M
+inline void refl_left(Mat M, int r0, int len, int c0, int c1, const double *v, double tau)
+{
+    if (tau == 0.0) return;
+    for (int j = c0; j < c1; j++) {
+        double s = 0.0;
+        for (int i = 0; i < len; i++) s += v[i] * M(r0 + i, j);
+        s *= tau;
+        for (int i = 0; i < len; i++) M(r0 + i, j) -= s * v[i];
+    }
+}
+// M(r0:r1, c0:c0+len) <- M (I - tau v v^T)
+inline void refl_right(Mat M, int c0, int len, int r0, int r1, const double *v, double tau)
+{
+    if (tau == 0.0) return;
+    for (int i = r0; i < r1; i++) {
+        double s = 0.0;
+        for (int j = 0; j < len; j++) s += M(i, c0 + j) * v[j];
+        s *= tau;
+        for (int j = 0; j < len; j++) M(i, c0 + j) -= s * v[j];
+    }
+}
+
+// Sum and product of the eigenvalues of the 2x2 pencil (a, b) with b upper triangular:
+// b11 b22 l^2 - (a11 b22 + a22 b11 - a21 b12) l + (a11 a22 - a12 a21) = 0
+inline void pencil2_sum_prod(double a11, double a12, double a21, double a22,
+    double b11, double b12, double b22, double &sum, double &prod)
+{
+    double den = b11 * b22;
+    sum = (a11 * b22 + a22 * b11 - a21 * b12) / den;
+    prod = (a11 * a22 - a12 * a21) / den;
+}
+
+} // namespace
+
+// Standardises the 2x2 diagonal block at p of the pencil (A,B) (B upper triangular):
+// real eigenvalues -> both A and B become upper triangular (returns 1);
+// complex pair -> B block diagonal with positive entries, A block full (returns 2).
+// (LAPACK dlagv2; reference process_2x2_block, cpu_utils.c:801-850.)
+static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
+{
+    double a11 = A(p, p), a12 = A(p, p + 1), a21 = A(p + 1, p), a22 = A(p + 1, p + 1);
+    double b11 = B(p, p), b12 = B(p, p + 1), b22 = B(p + 1, p + 1);
+    double sum, prod;
+    pencil2_sum_prod(a11, a12, a21, a22, b11, b12, b22, sum, prod);
+    double disc = 0.25 * sum * sum - prod;
+    if (disc >= 0.0) {
+        // real pair: lambda closer to a22/b22 first
+        double rt = std::sqrt(disc);
+        double l1 = 0.5 * sum + rt, l2 = 0.5 * sum - rt;
+        double lam = (std::fabs(l1 - a22 / b22) <= std::fabs(l2 - a22 / b22)) ? l1 : l2;
+        // right null vector x of M = A22 - lam B22
+        double m00 = a11 - lam * b11, m01 = a12 - lam * b12, m10 = a21, m11 = a22 - lam * b22;
+        double x0, x1;
+        if (std::hypot(m00, m01) >= std::hypot(m10, m11)) { x0 = m01; x1 = -m00; }
+        else { x0 = m11; x1 = -m10; }
+        double c, s, r;
+        givens(x0, x1, c, s, r);                  // [c s; -s c][x0; x1] = [r; 0]
+        // V = [c -s; s c] has first column x/|x|: apply M <- M V  (cols p, p+1)
+        rot_cols(A, p, p + 1, 0, std::min(n, p + 2), c, s);
+        rot_cols(B, p, p + 1, 0, p + 2, c, s);
+        rot_cols(Z, p, p + 1, 0, nq, c, s);
+        // rotate rows to annihilate B(p+1,p) (A(p+1,p) follows: A V e1 = lam B V e1)
+        double c2, s2, r2;
+        givens(B(p, p), B(p + 1, p), c2, s2, r2);
+        rot_rows(A, p, p + 1, p, n, c2, s2);
+        rot_rows(B, p, p + 1, p, n, c2, s2);
+        rot_cols(Q, p, p + 1, 0, nq, c2, s2);
+        B(p + 1, p) = 0.0; A(p + 1, p) = 0.0;
+        return 1;
+    }
+    // complex pair: B22 = U S V^T  ->  U^T B22 V diagonal (2x2 SVD of a triangular matrix)
+    double th = 0.5 * std::atan2(2.0 * b11 * b12, b11 * b11 - b12 * b12 - b22 * b22);
+    double cv = std::cos(th), sv = std::sin(th);          // V = [cv -sv; sv cv]
+    rot_cols(A, p, p + 1, 0, std::min(n, p + 2), cv, sv);
+    rot_cols(B, p, p + 1, 0, p + 2, cv, sv);
+    rot_cols(Z, p, p + 1, 0, nq, cv, sv);
+    double c2, s2, r2;
+    givens(B(p, p), B(p + 1, p), c2, s2, r2);             // columns of B22 V are orthogonal
+    rot_rows(A, p, p + 1, p, n, c2, s2);
+    rot_rows(B, p, p + 1, p, n, c2, s2);
+    rot_cols(Q, p, p + 1, 0, nq, c2, s2);
+    B(p + 1, p) = 0.0; B(p, p + 1) = 0.0;
+    for (int k = 0; k < 2; k++)
+        if (B(p + k, p + k) < 0.0) {              // positive diagonal: flip a column (Z diag(+-1))
+            for (int i = 0; i < std::min(n, p + 2); i++) A(i, p + k) = -A(i, p + k);
+            for (int i = 0; i <= p + k; i++) B(i, p + k) = -B(i, p + k);
+            for (int i = 0; i < nq; i++) Z(i, p + k) = -Z(i, p + k);
+        }
+    return 2;
+}
+
+// Eigenvalues (alpha_r + i alpha_i) / beta of a generalized Schur form (S quasi-triangular,
+// T upper triangular with standardised 2x2 blocks) -- reference common/math.c:148-176 (dlag2).
+void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_, int ldt,
+    double *ar, double *ai, double *be)
+{
+    Mat S{const_cast<double *>(S_), lds}, T{const_cast<double *>(T_), ldt};
+    for (int i = 0; i < n; i++) {
+        if (i + 1 < n && S(i + 1, i) != 0.0) {
+            double sum, prod;
+            pencil2_sum_prod(S(i, i), S(i, i + 1), S(i + 1, i), S(i + 1, i + 1),
+                T(i, i), T(i, i + 1), T(i + 1, i + 1), sum, prod);
+            double disc = prod - 0.25 * sum * sum;
+            double wi = disc > 0.0 ? std::sqrt(disc) : 0.0;
+            ar[i] = ar[i + 1] = 0.5 * sum; ai[i] = wi; ai[i + 1] = -wi; be[i] = be[i + 1] = 1.0;
+            i++;
+        } else { ar[i] = S(i, i); ai[i] = 0.0; be[i] = T(i, i); }
+    }
+}
+
+// Implicit double-shift QZ on a small Hessenberg-triangular pencil; Q <- Q*U1, Z <- Z*U2 with
+// U1^T A U2 quasi-triangular, U1^T B U2 triangular.  Q and Z have nq rows.  Returns 0 or the
+// (1-based) row where the iteration limit was hit.
+int gep_small_schur(int n, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
+    double *Z_, int ldz, int nq, double *ar, double *ai, double *be)
+{
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    const double ulp = DBL_EPSILON, safmin = DBL_MIN;
+    if (n == 0) return 0;
+    double bn = 0.0;
+    for (int j = 0; j < n; j++) for (int i = 0; i <= j; i++) bn = std::hypot(bn, B(i, j));
+    const double btol = std::max(safmin, ulp * bn);
+    for (int j = 0; j < n; j++) {               // clean below the (sub)diagonal
+        for (int i = j + 2; i < n; i++) A(i, j) = 0.0;
+        for (int i = j + 1; i < n; i++) B(i, j) = 0.0;
+    }
+    int ilast = n - 1, iiter = 0, total = 0;
+    const int maxit = 30 * std::max(10, n);
+    while (ilast >= 0) {
+        // ---- locate the active block [ifirst, ilast]
+        int ifirst = 0;
+        for (int j = ilast; j >= 1; j--) {
+            double tst = std::fabs(A(j, j)) + std::fabs(A(j - 1, j - 1));
+            if (tst == 0.0) tst = std::fabs(A(j, j - 1));
+            if (std::fabs(A(j, j - 1)) <= std::max(safmin, ulp * tst)) { A(j, j - 1) = 0.0; ifirst = j; break; }
+        }
+        if (ifirst == ilast) {                  // 1x1 block
+            if (B(ilast, ilast) < 0.0) {
+                for (int i = 0; i <= ilast; i++) { A(i, ilast) = -A(i, ilast); B(i, ilast) = -B(i, ilast); }
+                for (int i = 0; i < nq; i++) Z(i, ilast) = -Z(i, ilast);
+            }
+            ilast--; iiter = 0; continue;
+        }
+        // numerically singular B inside the block: perturb by u*||B|| (see the file header)
+        for (int j = ifirst; j <= ilast; j++)
+            if (std::fabs(B(j, j)) < btol) B(j, j) = (B(j, j) < 0.0) ? -btol : btol;
+        if (ifirst == ilast - 1) {              // 2x2 block
+            int kind = gep_standardise_2x2(n, A, B, Q, Z, nq, ifirst);
+            if (kind == 2) { ilast -= 2; iiter = 0; }
+            continue;                            // real pair: two 1x1 blocks on the next passes
+        }
+        if (++total > maxit) return ilast + 1;
+        iiter++;
+        // ---- shifts: eigenvalues of the trailing 2x2 pencil (their sum and product)
+        int const l = ifirst, m = ilast;
+        double sum, prod;
+        pencil2_sum_prod(A(m - 1, m - 1), A(m - 1, m), A(m, m - 1), A(m, m),
+            B(m - 1, m - 1), B(m - 1, m), B(m, m), sum, prod);
+        if (iiter % 10 == 0) {                  // exceptional shift pair
+            double e = (std::fabs(A(m, m - 1)) + std::fabs(A(m - 1, m - 2))) / std::fabs(B(m - 1, m - 1));
+            sum = 1.5 * e + A(m, m) / B(m, m); prod = 0.4375 * e * e + 0.25 * sum * sum;
+        }
+        // first column of (A B^-1 - s1)(A B^-1 - s2) (reference create_bulge, cpu_utils.c:880-918)
+        double z1_0 = A(l, l) / B(l, l), z1_1 = A(l + 1, l) / B(l, l);
+        double t1 = z1_1 / B(l + 1, l + 1), t0 = (z1_0 - B(l, l + 1) * t1) / B(l, l);
+        double v[3] = {
+            A(l, l) * t0 + A(l, l + 1) * t1 - sum * z1_0 + prod,
+            A(l + 1, l) * t0 + A(l + 1, l + 1) * t1 - sum * z1_1,
+            A(l + 2, l + 1) * t1 };
+        // ---- the QZ sweep (Golub & Van Loan Alg. 7.7.2)
+        for (int k = l; k <= m - 2; k++) {
+            double hv[3], beta, tau = house_first(3, v, hv, beta);
+            int const c0 = std::max(k - 1, l);
+            refl_left(A, k, 3, c0, n, hv, tau);
+            if (k > l) { A(k + 1, k - 1) = 0.0; A(k + 2, k - 1) = 0.0; }
+            refl_left(B, k, 3, k, n, hv, tau);
+            refl_right(Q, k, 3, 0, nq, hv, tau);
+            // zero B(k+2,k), B(k+2,k+1)
+            double row[3] = { B(k + 2, k), B(k + 2, k + 1), B(k + 2, k + 2) }, zv[3];
+            double tz = house_last(3, row, zv, beta);
+            refl_right(A, k, 3, 0, std::min(k + 4, m + 1), zv, tz);
+            refl_right(B, k, 3, 0, k + 3, zv, tz);
+            refl_right(Z, k, 3, 0, nq, zv, tz);
+            B(k + 2, k) = 0.0; B(k + 2, k + 1) = 0.0;
+            // zero B(k+1,k)
+            double row2[2] = { B(k + 1, k), B(k + 1, k + 1) }, zw[2];
+            double tw = house_last(2, row2, zw, beta);
+            refl_right(A, k, 2, 0, std::min(k + 4, m + 1), zw, tw);
+            refl_right(B, k, 2, 0, k + 2, zw, tw);
+            refl_right(Z, k, 2, 0, nq, zw, tw);
+            B(k + 1, k) = 0.0;
+            v[0] = A(k + 1, k); v[1] = A(k + 2, k); v[2] = (k < m - 2) ? A(k + 3, k) : 0.0;
+        }
+        {   // last step: rows m-1, m
+            double hv[2], beta, tau = house_first(2, v, hv, beta);
+            refl_left(A, m - 1, 2, m - 2, n, hv, tau);
+            A(m, m - 2) = 0.0;
+            refl_left(B, m - 1, 2, m - 1, n, hv, tau);
+            refl_right(Q, m - 1, 2, 0, nq, hv, tau);
+            double row2[2] = { B(m, m - 1), B(m, m) }, zw[2];
+            double tw = house_last(2, row2, zw, beta);
+            refl_right(A, m - 1, 2, 0, m + 1, zw, tw);
+            refl_right(B, m - 1, 2, 0, m + 1, zw, tw);
+            refl_right(Z, m - 1, 2, 0, nq, zw, tw);
+            B(m, m - 1) = 0.0;
+        }
+    }
+    gep_extract_eigenvalues(n, A_, lda, B_, ldb, ar, ai, be);
+    return 0;
+}
+
+// Reduction of (A,B), B upper triangular, to Hessenberg-triangular form on rows/columns
+// [ilo, ihi] by Givens rotations (LAPACK dgghrd, unblocked; reference cpu_utils.c:2681-2684).
+// Row rotations act on columns up to n-1, column rotations on rows 0..ihi; Q, Z have nq rows.
+void gep_ht_reduce(int n, int ilo, int ihi, double *A_, int lda, double *B_, int ldb,
+    double *Q_, int ldq, double *Z_, int ldz, int nq)
+{
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    for (int jc = ilo; jc <= ihi - 2; jc++) {
+        for (int jr = ihi; jr >= jc + 2; jr--) {
+            double c, s, r;
+            givens(A(jr - 1, jc), A(jr, jc), c, s, r);      // rows jr-1, jr kill A(jr, jc)
+            A(jr - 1, jc) = r; A(jr, jc) = 0.0;
+            rot_rows(A, jr - 1, jr, jc + 1, n, c, s);
+            rot_rows(B, jr - 1, jr, jr - 1, n, c, s);
+            rot_cols(Q, jr - 1, jr, 0, nq, c, s);
+            givens(B(jr, jr), B(jr, jr - 1), c, s, r);      // columns jr, jr-1 kill B(jr, jr-1)
+            B(jr, jr) = r; B(jr, jr - 1) = 0.0;
+            rot_cols(A, jr, jr - 1, 0, ihi + 1, c, s);
+            rot_cols(B, jr, jr - 1, 0, jr, c, s);
+            rot_cols(Z, jr, jr - 1, 0, nq, c, s);
+        }
+    }
+}
+
+// Aggressive early deflation on a host window of the pencil (reference
+// perform_aggressively_deflate, cpu_utils.c:2837-3046, generalized branches), without
+// reordering: the trailing run of eigenvalues whose spike entries are below the threshold is
+// deflated.  On return (S,T) = [HT (ns x ns) | *; 0 | Schur (nd x nd)], Q/Z the accumulated
+// transformations, spike[0] the new coupling entry, shifts as complex numbers alpha/beta.
+AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
+    double *Z_, int ldz, double sub, double thres, double *spike, double *sr, double *si)
+{
+    AedResult res{0, 0, 0};
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    for (int j = 0; j < nw; j++) for (int i = 0; i < nw; i++) { Q(i, j) = (i == j); Z(i, j) = (i == j); }
+    std::vector<double> ar(nw), ai(nw), be(nw);
+    int info = gep_small_schur(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, ar.data(), ai.data(), be.data());
+    if (info != 0) { res.failed = 1; return res; }
+    for (int j = 0; j < nw; j++) spike[j] = sub * Q(0, j);
+    int i = nw - 1, nd = 0;
+    while (i >= 0) {
+        bool two = (i >= 1 && A(i, i - 1) != 0.0);
+        bool ok = std::fabs(spike[i]) < thres && (!two || std::fabs(spike[i - 1]) < thres);
+        if (!ok) break;
+        nd += two ? 2 : 1; i -= two ? 2 : 1;
+    }
+    int const ns = nw - nd;
+    res.deflated = nd;
+    // shifts: finite eigenvalues of the undeflated part (of everything if that is too small)
+    {
+        int lo = 0, hi = (ns >= 2) ? ns : nw, cnt = 0;
+        std::vector<double> wr, wi;
+        for (int k = lo; k < hi; k++)
+            if (be[k] != 0.0) {
+                double re = ar[k] / be[k], im = ai[k] / be[k];
+                if (std::isfinite(re) && std::isfinite(im) && !(re == 0.0 && im == 0.0)) { wr.push_back(re); wi.push_back(im); }
+            }
+        cnt = (int)wr.size();
+        std::vector<int> idx(cnt);
+        for (int k = 0; k < cnt; k++) idx[k] = k;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            return std::fabs(wr[a]) + std::fabs(wi[a]) < std::fabs(wr[b]) + std::fabs(wi[b]); });
+        for (int k = 0; k < cnt; k++) { sr[k] = wr[idx[k]]; si[k] = wi[idx[k]]; }
+        for (int k = 0; k + 2 < cnt; k += 2)
+            if (si[k] != -si[k + 1]) {
+                double r0 = sr[k], i0 = si[k];
+                sr[k] = sr[k + 1]; sr[k + 1] = sr[k + 2]; sr[k + 2] = r0;
+                si[k] = si[k + 1]; si[k + 1] = si[k + 2]; si[k + 2] = i0;
+            }
+        res.shifts = cnt;
+    }
+    if (nd == 0) return res;
+    for (int j = ns; j < nw; j++) spike[j] = 0.0;
+    if (ns > 1 && sub != 0.0) {
+        // padded pencil: row/column 0 carries the spike, then dgghrd on [0, ns]
+        int const np = nw + 1;
+        std::vector<double> Ap((size_t)np * np, 0.0), Bp((size_t)np * np, 0.0), Qp((size_t)np * np, 0.0), Zp((size_t)np * np, 0.0);
+        Mat PA{Ap.data(), np}, PB{Bp.data(), np}, PQ{Qp.data(), np}, PZ{Zp.data(), np};
+        PB(0, 0) = 1.0; PQ(0, 0) = 1.0; PZ(0, 0) = 1.0;
+        for (int j = 0; j < nw; j++)
+            for (int r = 0; r < nw; r++) {
+                PA(r + 1, j + 1) = A(r, j); PB(r + 1, j + 1) = B(r, j);
+                PQ(r + 1, j + 1) = Q(r, j); PZ(r + 1, j + 1) = Z(r, j);
+            }
+        for (int r = 0; r < ns; r++) PA(r + 1, 0) = spike[r];
+        gep_ht_reduce(np, 0, ns, Ap.data(), np, Bp.data(), np, Qp.data(), np, Zp.data(), np, np);
+        for (int j = 0; j < nw; j++)
+            for (int r = 0; r < nw; r++) {
+                A(r, j) = PA(r + 1, j + 1); B(r, j) = PB(r + 1, j + 1);
+                Q(r, j) = PQ(r + 1, j + 1); Z(r, j) = PZ(r + 1, j + 1);
+            }
+        spike[0] = PA(1, 0);
+        for (int r = 1; r < ns; r++) spike[r] = 0.0;
+        // exact structure
+        for (int j = 0; j < ns; j++) {
+            for (int r = j + 2; r < nw; r++) A(r, j) = 0.0;
+            for (int r = j + 1; r < nw; r++) B(r, j) = 0.0;
+        }
+    }
+    return res;
+}
+
+}} // namespace sn::host
+
+// ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
+extern "C" {
+__attribute__((visibility("default")))
+int sn_internal_gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, double *ar, double *ai, double *be)
+{ return sn::host::gep_small_schur(n, A, lda, B, ldb, Q, ldq, Z, ldz, n, ar, ai, be); }
+__attribute__((visibility("default")))
+void sn_internal_gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,
+    double *Q, int ldq, double *Z, int ldz)
+{ sn::host::gep_ht_reduce(n, ilo, ihi, A, lda, B, ldb, Q, ldq, Z, ldz, n); }
+__attribute__((visibility("default")))
+int sn_internal_gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si, int *out3)
+{
+    sn::host::AedResult r = sn::host::gep_aed_window(nw, A, lda, B, ldb, Q, ldq, Z, ldz, sub, thres, spike, sr, si);
+    out3[0] = r.deflated; out3[1] = r.shifts; out3[2] = r.failed;
+    return 0;
+}
+}

@@ -1,0 +1,113 @@
+"""CPU: host-side kernels of the generalized (QZ) path through internal hooks, against
+scipy/LAPACK (generalized eigenvalues of the same pencil) and the invariants of a generalized
+Schur decomposition Q S Z^T = A, Q T Z^T = B."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+import oracle as O
+import starneig_amd as S
+from helpers import U
+
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def lib():
+    L = S.lib.load()
+    L.sn_internal_gep_small_schur.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [dp, dp, dp]
+    L.sn_internal_gep_ht_reduce.argtypes = [C.c_int, C.c_int, C.c_int] + [dp, C.c_int] * 4
+    L.sn_internal_gep_aed_window.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [C.c_double, C.c_double, dp, dp, dp,
+                                                                              C.POINTER(C.c_int)]
+    return L
+
+
+def random_ht_pencil(n, seed=2019):
+    """test driver's generalized Schur input: random Hessenberg + random upper triangular
+    (test/common/init.c:122-138,159-175), LCG stream"""
+    O.lib().oracle_init_prand(seed)
+    A = np.zeros((n, n), order="F"); B = np.zeros((n, n), order="F")
+    O.lib().oracle_fill_random_hessenberg(n, P(A), n)
+    rng = np.random.RandomState(seed)
+    B[:] = np.triu(rng.uniform(-1, 1, (n, n)))
+    return A, B
+
+
+def check_gschur(A0, B0, Sm, Tm, Q, Z, tol=500):
+    n = A0.shape[0]
+    assert np.all(np.tril(Sm, -2) == 0.0) and np.all(np.tril(Tm, -1) == 0.0)
+    sub = np.diag(Sm, -1)
+    assert not np.any((sub[:-1] != 0) & (sub[1:] != 0))
+    for i in np.nonzero(sub)[0]:                         # standardised 2x2 blocks (hooks.c:571-620)
+        assert Tm[i, i + 1] == 0.0 and Tm[i, i] > 0 and Tm[i + 1, i + 1] > 0
+    assert np.linalg.norm(Q @ Sm @ Z.T - A0) <= tol * U * np.linalg.norm(A0)
+    assert np.linalg.norm(Q @ Tm @ Z.T - B0) <= tol * U * np.linalg.norm(B0)
+    assert np.linalg.norm(Q @ Q.T - np.eye(n)) <= tol * U * np.sqrt(n)
+    assert np.linalg.norm(Z @ Z.T - np.eye(n)) <= tol * U * np.sqrt(n)
+
+
+def eig_match(ar, ai, be, A0, B0):
+    ev = (ar + 1j * ai) / be
+    ref = sl.eigvals(A0, B0)
+    return O.match_eigenvalues(ev, ref)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 11, 40, 120])
+def test_small_qz_against_scipy(n):
+    A0, B0 = random_ht_pencil(n)
+    Sm, Tm = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.asfortranarray(np.eye(n)); Z = np.asfortranarray(np.eye(n))
+    ar = np.zeros(n); ai = np.zeros(n); be = np.zeros(n)
+    assert lib().sn_internal_gep_small_schur(n, P(Sm), n, P(Tm), n, P(Q), n, P(Z), n, P(ar), P(ai), P(be)) == 0
+    check_gschur(A0, B0, Sm, Tm, Q, Z)
+    assert np.all(be > 0)
+    assert eig_match(ar, ai, be, A0, B0) < 1e7           # pencils with tiny |T_ii| are ill-conditioned
+    i = 0
+    while i < n:
+        if ai[i] != 0:
+            assert ai[i] > 0 and ai[i + 1] == -ai[i]; i += 2
+        else:
+            i += 1
+
+
+def test_ht_reduce_restores_structure():
+    n = 30
+    rng = np.random.RandomState(1)
+    A0 = np.asfortranarray(rng.randn(n, n)); B0 = np.asfortranarray(np.triu(rng.randn(n, n)))
+    A, B = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.asfortranarray(np.eye(n)); Z = np.asfortranarray(np.eye(n))
+    lib().sn_internal_gep_ht_reduce(n, 0, n - 1, P(A), n, P(B), n, P(Q), n, P(Z), n)
+    assert np.abs(np.tril(A, -2)).max() == 0.0 and np.abs(np.tril(B, -1)).max() == 0.0
+    assert np.linalg.norm(Q @ A @ Z.T - A0) <= 200 * U * np.linalg.norm(A0)
+    assert np.linalg.norm(Q @ B @ Z.T - B0) <= 200 * U * np.linalg.norm(B0)
+
+
+@pytest.mark.parametrize("nw,sub", [(40, 1e-6), (90, 1e-2)])
+def test_gep_aed_window_invariants(nw, sub):
+    A0, B0 = random_ht_pencil(nw, seed=7)
+    thres = U * np.linalg.norm(A0) * 1e4
+    A, B = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.zeros((nw, nw), order="F"); Z = np.zeros((nw, nw), order="F")
+    spike = np.zeros(nw); sr = np.zeros(nw); si = np.zeros(nw); out = (C.c_int * 3)()
+    lib().sn_internal_gep_aed_window(nw, P(A), nw, P(B), nw, P(Q), nw, P(Z), nw, sub, thres,
+                                     P(spike), P(sr), P(si), out)
+    nd, nsh, failed = out[0], out[1], out[2]
+    assert failed == 0
+    assert np.linalg.norm(Q @ Q.T - np.eye(nw)) <= 500 * U * np.sqrt(nw)
+    assert np.linalg.norm(Z @ Z.T - np.eye(nw)) <= 500 * U * np.sqrt(nw)
+    if nd == 0:
+        return
+    ns = nw - nd
+    assert np.linalg.norm(Q @ A @ Z.T - A0) <= 1000 * U * np.linalg.norm(A0)
+    assert np.linalg.norm(Q @ B @ Z.T - B0) <= 1000 * U * np.linalg.norm(B0)
+    assert np.all(np.tril(A, -2) == 0.0) and np.all(np.tril(B, -1) == 0.0)
+    assert np.all(A[ns:, :ns] == 0.0)
+    full = sub * Q[0, :]
+    assert np.all(spike[1:] == 0.0)
+    assert abs(abs(spike[0]) - np.linalg.norm(full[:ns])) <= 1e3 * U * abs(sub)
+    assert np.all(np.abs(full[ns:]) < thres * 1.001)
