@@ -1,0 +1,37 @@
+/* Generalized eigenvalue problem, shared memory (one node).  Replaces: reference
+ * src/include/starneig/gep_sm.h:164-170 (Schur) and :503-510 (expert variant).  Only the
+ * Schur (QZ) leg of the generalized chain is on this path (BASELINE config 5: the input is
+ * already a Hessenberg-triangular pencil); starneig_GEP_SM_HessenbergTriangular,
+ * _ReorderSchur and _Eigenvectors are outside it.  All arrays are HOST pointers,
+ * column-major, results are written in place, exactly as in the reference. */
+#ifndef STARNEIG_AMD_GEP_SM_H
+#define STARNEIG_AMD_GEP_SM_H
+#include <starneig/error.h>
+#include <starneig/expert.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* (H, R) upper Hessenberg / upper triangular <- (S, T) generalized real Schur form
+ * (S quasi-triangular, T upper triangular, 2x2 blocks standardised: T diagonal and
+ * non-negative there), Q <- Q*U1, Z <- Z*U2 so that Q (S,T) Z^T = Q_in (H,R) Z_in^T.
+ * The eigenvalues are (real[i] + i*imag[i]) / beta[i] in diagonal order.
+ * Errors: n<1 -> -1, H NULL -> -2, ldH<n -> -3, R NULL -> -4, ldR<n -> -5, Q NULL -> -6,
+ * ldQ<n -> -7, Z NULL -> -8, ldZ<n -> -9 (schur/interface.c:283-291), real/imag/beta
+ * NULL -> -10/-11/-12; STARNEIG_NOT_INITIALIZED; STARNEIG_DID_NOT_CONVERGE. */
+starneig_error_t starneig_GEP_SM_Schur(
+    int n, double H[], int ldH, double R[], int ldR,
+    double Q[], int ldQ, double Z[], int ldZ,
+    double real[], double imag[], double beta[]);
+
+/* Same with a configuration structure; argument numbers in the error codes shift by one
+ * (schur/interface.c:247-255). */
+starneig_error_t starneig_GEP_SM_Schur_expert(
+    struct starneig_schur_conf *conf, int n, double H[], int ldH, double R[], int ldR,
+    double Q[], int ldQ, double Z[], int ldZ,
+    double real[], double imag[], double beta[]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -5,4 +5,5 @@
 #include <starneig/node.h>
 #include <starneig/expert.h>
 #include <starneig/sep_sm.h>
+#include <starneig/gep_sm.h>
 #endif

@@ -57,6 +57,16 @@ starneig_error_t starneig_amd_schur_device(
     int n, double *dH, int ldH, double *dQ, int ldQ, double *real, double *imag,
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
+/* Generalized twin (BASELINE config 5): the device-resident Hessenberg-triangular pencil
+ * (dH, dR) <- generalized real Schur form, dQ <- dQ*U1, dZ <- dZ*U2 (either may be NULL).
+ * real/imag/beta are HOST arrays of length n (all NULL = not extracted).  Same conf and
+ * stats layout as starneig_amd_schur_device.  Replaces the generalized branches of
+ * schur/core.c:2342-2514 and schur/cpu_utils.c:1168-1810. */
+starneig_error_t starneig_amd_gep_schur_device(
+    int n, double *dH, int ldH, double *dR, int ldR, double *dQ, int ldQ, double *dZ, int ldZ,
+    double *real, double *imag, double *beta,
+    struct starneig_schur_conf *conf, void *stream, double *stats);
+
 /* fp64 MFMA GEMM, BLAS dgemm semantics on device pointers (the kernel behind
  * rows H4-H8 and S3; replaces cblas_dgemm/cublasDgemm call sites). */
 starneig_error_t starneig_amd_dgemm_device(
@@ -83,6 +93,20 @@ starneig_error_t starneig_amd_check_device(
     int n, double const *dQ, int ldQ, double const *dH, int ldH,
     double const *dA0, int ldA0, double *dWork1, double *dWork2,
     double out[3], void *stream);
+
+/* The reference test driver's random Hessenberg-triangular pencil (test/schur/
+ * experiment.c:203-207: generate_random_hessenberg then generate_random_uptriag on the one
+ * LCG stream, test/common/init.c:122-138,159-175), generated directly in HBM. */
+starneig_error_t starneig_amd_lcg_pencil_device(
+    int n, unsigned seed, double *dH, int ldH, double *dR, int ldR, void *stream);
+
+/* Acceptance checks of a two-sided decomposition on the GPU (test/common/checks.c):
+ * out[0] = 2^52 ||Q S Z^T - A0||_F / ||A0||_F, out[1] = 2^52 ||Q Q^T - I||_F / sqrt(n),
+ * out[2] = the same for Z, out[3] = non-zeros of S below the first sub-diagonal.
+ * dWork1/dWork2 are n*n scratch. */
+starneig_error_t starneig_amd_check_pencil_device(
+    int n, double const *dQ, int ldQ, double const *dS, int ldS, double const *dZ, int ldZ,
+    double const *dA0, int ldA0, double *dWork1, double *dWork2, double out[4], void *stream);
 
 /* hessenberg/interface.c:74-78 */
 int starneig_amd_default_panel_width(int n);

@@ -51,6 +51,12 @@ def lib():
         L.oracle_extract_eigenvalues.argtypes = [C.c_int, dp, C.c_int, dp, dp]
         L.oracle_check_schur_form.argtypes = [C.c_int, dp, C.c_int]
         L.oracle_check_schur_form.restype = C.c_int
+        L.oracle_fill_random_uptriag.argtypes = [C.c_int, dp, C.c_int]
+        L.oracle_gep_schur.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, dp, dp]
+        L.oracle_gep_schur.restype = C.c_int
+        L.oracle_gep_extract_eigenvalues.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, dp, dp]
+        L.oracle_check_gep_schur_form.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int]
+        L.oracle_check_gep_schur_form.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -143,6 +149,58 @@ def extract_eigenvalues(S):
 
 def check_schur_form(S):
     return lib().oracle_check_schur_form(S.shape[1], _p(S), S.shape[0])
+
+
+def random_pencil(n, seed=2019, ld=None):
+    """The test driver's random Hessenberg-triangular pencil (test/schur/experiment.c:203-207):
+    generate_random_hessenberg, then generate_random_uptriag on the same LCG stream."""
+    ld = ld or ld_for(n)
+    H = np.zeros((ld, n), order="F")
+    R = np.zeros((ld, n), order="F")
+    lib().oracle_init_prand(seed)
+    lib().oracle_fill_random_hessenberg(n, _p(H), ld)
+    lib().oracle_fill_random_uptriag(n, _p(R), ld)
+    return H, R
+
+
+def random_pencil_wellcond(n, seed=2019, ld=None):
+    """Same LCG data with a well-conditioned triangular factor (tests/golden/make_golden_gep.py):
+    strict upper part / sqrt(n), diagonal 1 + |r_ii| -- eigenvalues comparable to ~1e4 u."""
+    H, R = random_pencil(n, seed, ld)
+    Rw = np.zeros_like(R)
+    Rw[:n] = np.triu(R[:n], 1) / np.sqrt(n) + np.diag(1.0 + np.abs(np.diag(R[:n])))
+    return H, Rw
+
+
+def gep_schur(H, R, Q, Z):
+    """In place: (H, R) -> generalized real Schur form, Q <- Q U1, Z <- Z U2.
+    Returns (info, alpha_r, alpha_i, beta)."""
+    n = H.shape[1]
+    ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+    dp = C.POINTER(C.c_double)
+    info = lib().oracle_gep_schur(n, _p(H), H.shape[0], _p(R), R.shape[0], _p(Q), Q.shape[0],
+                                  _p(Z), Z.shape[0], ar.ctypes.data_as(dp), ai.ctypes.data_as(dp),
+                                  be.ctypes.data_as(dp))
+    return info, ar, ai, be
+
+
+def gep_extract_eigenvalues(S, T):
+    n = S.shape[1]
+    ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+    dp = C.POINTER(C.c_double)
+    lib().oracle_gep_extract_eigenvalues(n, _p(S), S.shape[0], _p(T), T.shape[0],
+                                         ar.ctypes.data_as(dp), ai.ctypes.data_as(dp), be.ctypes.data_as(dp))
+    return ar, ai, be
+
+
+def check_gep_schur_form(S, T):
+    return lib().oracle_check_gep_schur_form(S.shape[1], _p(S), S.shape[0], _p(T), T.shape[0])
+
+
+def pencil_residual_u(Q, S, Z, A):
+    """2^52 ||Q S Z^T - A||_F / ||A||_F (test/common/checks.c two-sided residual)."""
+    n = A.shape[1]
+    return float(np.linalg.norm(Q[:n] @ S[:n] @ Z[:n].T - A[:n]) / np.linalg.norm(A[:n]) * 2.0 ** 52)
 
 
 def match_eigenvalues(ev_a, ev_b):

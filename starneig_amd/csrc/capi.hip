@@ -89,6 +89,7 @@ SN_API void starneig_node_finalize(void)
     SN_HIP_CHECK(hipDeviceSynchronize());
     sn::hessenberg_release_workspace();
     sn::schur_release_workspace();
+    sn::gep_schur_release_workspace();
     g_node.initialized = false;
 }
 
@@ -112,6 +113,7 @@ SN_API void starneig_amd_release_workspace(void)
 {
     sn::hessenberg_release_workspace();
     sn::schur_release_workspace();
+    sn::gep_schur_release_workspace();
 }
 
 // ---- host-array interface (in place, like the reference) ----------------------
@@ -310,7 +312,97 @@ SN_API starneig_error_t starneig_SEP_SM_Reduce(
     return starneig_SEP_SM_Schur(n, A, ldA, Q, ldQ, real, imag);
 }
 
+// ---- generalized Schur (gep_sm.h) ---------------------------------------------
+SN_API starneig_error_t starneig_GEP_SM_Schur_expert(
+    struct starneig_schur_conf *conf, int n, double H[], int ldH, double R[], int ldR,
+    double Q[], int ldQ, double Z[], int ldZ, double real[], double imag[], double beta[])
+{
+    if (n < 1)      return -2;
+    if (H == NULL)  return -3;
+    if (ldH < n)    return -4;
+    if (R == NULL)  return -5;
+    if (ldR < n)    return -6;
+    if (Q == NULL)  return -7;
+    if (ldQ < n)    return -8;
+    if (Z == NULL)  return -9;
+    if (ldZ < n)    return -10;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::SchurParams prm;
+    int rc = schur_params_from_conf(conf, prm);
+    if (rc != STARNEIG_SUCCESS) return rc;
+
+    int const ld = (int)sn::roundup(n, 16);
+    size_t const bytes = (size_t)ld * n * sizeof(double);
+    double *host[4] = {H, R, Q, Z};
+    int const lds[4] = {ldH, ldR, ldQ, ldZ};
+    double *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        SN_HIP_CHECK(hipMalloc((void **)&dev[i], bytes));
+        SN_HIP_CHECK(hipMemset(dev[i], 0, bytes));
+        SN_HIP_CHECK(hipMemcpy2D(dev[i], (size_t)ld * 8, host[i], (size_t)lds[i] * 8, (size_t)n * 8, n,
+            hipMemcpyHostToDevice));
+    }
+    if (real == NULL || imag == NULL || beta == NULL) real = imag = beta = nullptr;
+    rc = sn::gep_schur_device(nullptr, n, dev[0], ld, dev[1], ld, dev[2], ld, dev[3], ld,
+        real, imag, beta, prm, nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < 4; i++) {
+        SN_HIP_CHECK(hipMemcpy2D(host[i], (size_t)lds[i] * 8, dev[i], (size_t)ld * 8, (size_t)n * 8, n,
+            hipMemcpyDeviceToHost));
+        SN_HIP_CHECK(hipFree(dev[i]));
+    }
+    return rc;
+}
+
+SN_API starneig_error_t starneig_GEP_SM_Schur(
+    int n, double H[], int ldH, double R[], int ldR, double Q[], int ldQ, double Z[], int ldZ,
+    double real[], double imag[], double beta[])
+{
+    if (n < 1)      return -1;
+    if (H == NULL)  return -2;
+    if (ldH < n)    return -3;
+    if (R == NULL)  return -4;
+    if (ldR < n)    return -5;
+    if (Q == NULL)  return -6;
+    if (ldQ < n)    return -7;
+    if (Z == NULL)  return -8;
+    if (ldZ < n)    return -9;
+    if (real == NULL) return -10;
+    if (imag == NULL) return -11;
+    if (beta == NULL) return -12;
+    return starneig_GEP_SM_Schur_expert(NULL, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta);
+}
+
 // ---- device-pointer extension -------------------------------------------------
+
+SN_API starneig_error_t starneig_amd_gep_schur_device(
+    int n, double *dH, int ldH, double *dR, int ldR, double *dQ, int ldQ, double *dZ, int ldZ,
+    double *real, double *imag, double *beta,
+    struct starneig_schur_conf *conf, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (dH == NULL)            return -2;
+    if (ldH < n)               return -3;
+    if (dR == NULL)            return -4;
+    if (ldR < n)               return -5;
+    if (dQ != NULL && ldQ < n) return -7;
+    if (dZ != NULL && ldZ < n) return -9;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::SchurParams prm;
+    int rc = schur_params_from_conf(conf, prm);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    sn::SchurStats st;
+    hipStream_t s = (hipStream_t)stream;
+    if (real == NULL || imag == NULL || beta == NULL) real = imag = beta = nullptr;
+    rc = sn::gep_schur_device(s, n, dH, ldH, dR, ldR, dQ, ldQ, dZ, ldZ, real, imag, beta, prm, &st);
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    if (stats) {
+        stats[0] = st.total_ms; stats[1] = st.sweeps; stats[2] = st.aeds;
+        stats[3] = st.small_solves; stats[4] = st.chase_launches; stats[5] = st.gemm_flops;
+        stats[6] = st.aed_host_s; stats[7] = st.wait_s;
+    }
+    return rc;
+}
 
 SN_API starneig_error_t starneig_amd_schur_device(
     int n, double *dH, int ldH, double *dQ, int ldQ, double *real, double *imag,
@@ -424,6 +516,19 @@ SN_API starneig_error_t starneig_amd_lcg_fill_device(
     return STARNEIG_SUCCESS;
 }
 
+SN_API starneig_error_t starneig_amd_lcg_pencil_device(
+    int n, unsigned seed, double *dH, int ldH, double *dR, int ldR, void *stream)
+{
+    if (n < 1) return -1;
+    if (dH == NULL) return -3;
+    if (ldH < n) return -4;
+    if (dR == NULL) return -5;
+    if (ldR < n) return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::lcg_pencil((hipStream_t)stream, n, seed, dH, ldH, dR, ldR);
+    return STARNEIG_SUCCESS;
+}
+
 SN_API starneig_error_t starneig_amd_set_matrix_device(
     int m, int n, double value, double diag, double *dA, int ldA, void *stream)
 {
@@ -462,6 +567,37 @@ SN_API starneig_error_t starneig_amd_check_device(
     out[0] = std::ldexp(std::sqrt(h[0]) / std::sqrt(h[1]), 52);
     out[1] = std::ldexp(std::sqrt(h[2]) / std::sqrt((double)n), 52);
     out[2] = h[3];
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_amd_check_pencil_device(
+    int n, double const *dQ, int ldQ, double const *dS, int ldS, double const *dZ, int ldZ,
+    double const *dA0, int ldA0, double *dWork1, double *dWork2, double out[4], void *stream)
+{
+    if (n < 1) return -1;
+    if (!dQ || !dS || !dZ || !dA0 || !dWork1 || !dWork2 || !out) return STARNEIG_INVALID_ARGUMENTS;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    hipStream_t s = (hipStream_t)stream;
+    double *acc = nullptr;
+    SN_HIP_CHECK(hipMalloc((void **)&acc, 5 * sizeof(double)));
+    SN_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(double), s));
+    sn::dgemm(s, 'N', 'N', n, n, n, 1.0, dQ, ldQ, dS, ldS, 0.0, dWork1, n);
+    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dWork1, n, dZ, ldZ, 0.0, dWork2, n);
+    sn::sumsq_diff(s, n, n, dWork2, n, dA0, ldA0, 0.0, acc + 0);
+    sn::sumsq_diff(s, n, n, dA0, ldA0, nullptr, 0, 0.0, acc + 1);
+    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dQ, ldQ, dQ, ldQ, 0.0, dWork1, n);
+    sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 2);
+    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dZ, ldZ, dZ, ldZ, 0.0, dWork1, n);
+    sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 3);
+    sn::count_below(s, n, dS, ldS, acc + 4);
+    double h[5];
+    SN_HIP_CHECK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, s));
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    SN_HIP_CHECK(hipFree(acc));
+    out[0] = std::ldexp(std::sqrt(h[0]) / std::sqrt(h[1]), 52);
+    out[1] = std::ldexp(std::sqrt(h[2]) / std::sqrt((double)n), 52);
+    out[2] = std::ldexp(std::sqrt(h[3]) / std::sqrt((double)n), 52);
+    out[3] = h[4];
     return STARNEIG_SUCCESS;
 }
 

@@ -103,5 +103,11 @@ struct SchurStats {
 int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
     double *real, double *imag, SchurParams const &params, SchurStats *stats);
 void schur_release_workspace();
+// Generalized twin (schur_gep.hip): (dA, dB) Hessenberg-triangular -> generalized Schur form
+int gep_schur_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,
+    double *dQ, int ldQ, double *dZ, int ldZ, double *real, double *imag, double *beta,
+    SchurParams const &params, SchurStats *stats);
+void gep_schur_release_workspace();
+void lcg_pencil(hipStream_t s, int n, unsigned seed, double *H, int ldh, double *R, int ldr);
 
 } // namespace sn

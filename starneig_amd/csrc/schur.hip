@@ -16,6 +16,7 @@
 #include "common.h"
 #include "schur_host.h"
 #include "dgemm_tile.h"
+#include "schur_common.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -31,47 +32,10 @@ void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double co
 constexpr int WS_MAX = 96;          // diagonal window (rows) held in LDS
 constexpr int NB_MAX = 15;          // bulges per chain: 3*NB_MAX+1 <= WS_MAX/2 + ...
 constexpr int LDW = WS_MAX + 1;     // odd leading dimension: conflict-free row AND column walks
-constexpr int TASK_RING = 32;      // pinned task lists in flight
 constexpr int CHASE_THREADS = 1024; // 16 waves share one window
 constexpr int UPDATE_LDS_BYTES_L = GemmCfg<128, 128, 16, true, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, 128, 16, false, false>::LDS_BYTES;
 constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 8 * NB_MAX + 16) * 8;
-
-struct ChaseTask {
-    int lo;         // first row/column of the window in H
-    int n;          // window size
-    int nb;         // bulges in this chain
-    int shift_off;  // index of the chain's first shift
-    int flags;      // 1 = introduce, 2 = finalize
-    int right;      // column where the trailing bulge of the chain stops (non-finalize windows)
-};
-
-// One step of a sweep: every chain in flight advances by one window.  The window of the
-// k-th active chain is a pure function of these integers, so the chase kernel and the update
-// kernels derive it on the device (no per-step task upload).
-struct SweepStep {
-    int ilo, ihi;           // active block
-    int ws, nbc, adv, gap;  // window size, bulges per chain, columns per step, steps between chains
-    int nbulges;            // total bulges of the sweep
-    int steps_per_chain;
-    int t;                  // step index
-    int cmin, ntasks;       // chains cmin .. cmin+ntasks-1 are in flight
-};
-
-__host__ __device__ inline ChaseTask make_task(SweepStep const &st, int k)
-{
-    int const c = st.cmin + k, p = st.t - c * st.gap;
-    ChaseTask task;
-    task.lo = st.ilo + p * st.adv;
-    int const rem = st.nbulges - c * st.nbc;
-    task.nb = rem < st.nbc ? rem : st.nbc;
-    task.shift_off = 2 * c * st.nbc;
-    task.flags = (p == 0) ? 1 : 0;
-    if (task.lo + st.ws >= st.ihi) { task.flags |= 2; task.n = st.ihi - task.lo; }
-    else task.n = st.ws;
-    task.right = st.adv;
-    return task;
-}
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
 __device__ __forceinline__ void shift_vector(double const *W, double sr1, double si1,
@@ -86,29 +50,6 @@ __device__ __forceinline__ void shift_vector(double const *W, double sr1, double
     v[0] = (h11 - sr1) * ((h11 - sr2) / s) - si1 * (si2 / s) + h12 * h21s + h13 * h31s;
     v[1] = h21s * (h11 + h22 - sr1 - sr2) + h23 * h31s;
     v[2] = h31s * (h11 + h33 - sr1 - sr2) + h21s * h32;
-}
-
-// Householder reflector I - tau [1;v1;v2][1;v1;v2]^T mapping x to beta e1 (len 2 or 3).
-// x is scaled by its largest entry first: bulges that pass an (almost) converged part of
-// the matrix shrink to 1e-150 and below, where x^2 would lose its bits to underflow
-// (LAPACK dlarfg handles the same situation with its safmin rescaling loop).
-__device__ __forceinline__ void small_reflector(int len, double const *x,
-    double &beta, double &v1, double &v2, double &tau)
-{
-    double x0 = x[0], x1 = x[1], x2 = len == 3 ? x[2] : 0.0;
-    double const m = fmax(fabs(x0), fmax(fabs(x1), fabs(x2)));
-    // (entries below 1e-290 cannot be scaled safely and are dropped: they are far below any
-    // deflation threshold)
-    if ((x1 == 0.0 && x2 == 0.0) || !(m > 1e-290) || !(fmax(fabs(x1), fabs(x2)) > 1e-290)) {
-        beta = x0; v1 = v2 = 0.0; tau = 0.0; return;
-    }
-    double const im = 1.0 / m;
-    double a = x0 * im, b1 = x1 * im, b2 = x2 * im;
-    double bs = -copysign(sqrt(a * a + b1 * b1 + b2 * b2), a);
-    tau = (bs - a) / bs;
-    double sc = 1.0 / (a - bs);
-    v1 = b1 * sc; v2 = b2 * sc;
-    beta = bs * m;
 }
 
 // One workgroup chases one chain of bulges through one diagonal window held in LDS

@@ -1,0 +1,603 @@
+// Multi-shift QZ with aggressive early deflation on one MI355X: generalized Schur reduction of
+// a Hessenberg-triangular pencil (A, B) -- BASELINE config 5, row S9 of SURVEY 8a.
+//
+// Reference: the same state machine as the standard case (schur/core.c:2226-2336) with the
+// generalized branches of the window kernels (schur/cpu_utils.c:1168-1810: left reflectors
+// from A's bulge columns, right reflectors that restore B's triangularity,
+// create_right_reflector :998-1040).  The design mirrors schur.hip: A, B, Q and Z never leave
+// HBM; one workgroup chases one chain of bulges through a 64-row diagonal window of the
+// pencil held in LDS together with BOTH accumulated orthogonal factors (4 x 64 x 65 doubles =
+// 133 KB of the 160 KB LDS); all off-diagonal updates are in-place fp64-MFMA GEMMs on a
+// near/far stream pair.  AED windows and small blocks are reduced on the host
+// (schur_host_gep.hip).  Not rebuilt in this revision: the reference's infinite-eigenvalue
+// deflation (push_inf_*, cpu_utils.c:360-799) -- a numerically singular B is treated as a
+// perturbation of size u*||B||_F.
+#include "common.h"
+#include "schur_host.h"
+#include "dgemm_tile.h"
+#include "schur_common.h"
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <cfloat>
+#include <chrono>
+#include <starneig/error.h>
+
+namespace sn {
+
+void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
+    double ident, double *acc);
+
+constexpr int GWS = 64;             // diagonal window of the pencil held in LDS
+constexpr int GNB = 10;             // bulges per chain: 6*GNB + 1 <= GWS
+constexpr int GLD = GWS + 1;        // odd leading dimension: conflict-free row AND column walks
+constexpr int GEP_CHASE_THREADS = 1024;
+constexpr int GEP_CHASE_LDS_BYTES = (4 * GWS * GLD + 8 * GNB + 16) * 8;
+constexpr int GEP_LDS_BYTES_L = GemmCfg<64, 128, 16, true, false>::LDS_BYTES;
+constexpr int GEP_LDS_BYTES_R = GemmCfg<128, 64, 16, false, false>::LDS_BYTES;
+
+// First column of (A B^-1 - s1 I)(A B^-1 - s2 I) for the leading 3x3 of a Hessenberg-
+// triangular pencil (Golub & Van Loan Alg. 7.7.2 written for a shift pair; the reference
+// gets the same vector from its bulge-introduction branch, cpu_utils.c:1259-1330).
+__device__ __forceinline__ void gep_shift_vector(double const *A, double const *B,
+    double sr1, double si1, double sr2, double si2, double *v)
+{
+    double const b00 = B[0], b01 = B[GLD], b11 = B[GLD + 1];
+    if (b00 == 0.0 || b11 == 0.0) { v[0] = v[1] = v[2] = 0.0; return; }
+    double const sum = sr1 + sr2, prod = sr1 * sr2 - si1 * si2;
+    double const a00 = A[0], a10 = A[1], a01 = A[GLD], a11 = A[GLD + 1], a21 = A[GLD + 2];
+    double const z0 = a00 / b00, z1 = a10 / b00;
+    double const t1 = z1 / b11, t0 = (z0 - b01 * t1) / b00;
+    v[0] = a00 * t0 + a01 * t1 - sum * z0 + prod;
+    v[1] = a10 * t0 + a11 * t1 - sum * z1;
+    v[2] = a21 * t1;
+}
+
+// One workgroup chases one chain of bulges through one diagonal window of the pencil.
+// Per column step: (1) one lane per bulge builds the left reflector from A's bulge column,
+// (2) all lanes apply it to the rows of A and B and accumulate it into Uq, (3) one lane per
+// bulge builds the right reflector that annihilates B's fill-in (its first column is
+// orthogonal to rows 2,3 of B's 3x3 block), (4) all lanes apply it to the columns of A, B
+// and accumulate it into Uz.  Bulges sit 3 columns apart so the reflectors of one step
+// touch disjoint rows/columns.
+__global__ __launch_bounds__(GEP_CHASE_THREADS)
+void gep_chase_kernel(SweepStep const step, double *__restrict__ Ag, int ldA,
+    double *__restrict__ Bg, int ldB, double *__restrict__ Uout,
+    double const *__restrict__ sr, double const *__restrict__ si)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *WA = lds, *WB = WA + GWS * GLD, *UQ = WB + GWS * GLD, *UZ = UQ + GWS * GLD;
+    double *R = UZ + GWS * GLD;                 // per bulge {v1,v2,tau, w1,w2,tauz}
+    int *Ri = reinterpret_cast<int *>(R + 6 * GNB);     // per bulge {row0, len}
+    ChaseTask const t = make_task(step, blockIdx.x);
+    int const n = t.n, nb = t.nb, tid = threadIdx.x;
+    bool const introduce = t.flags & 1, finalize = t.flags & 2;
+
+    for (int idx = tid; idx < n * n; idx += GEP_CHASE_THREADS) {
+        int r = idx % n, c = idx / n;
+        WA[c * GLD + r] = Ag[(size_t)(t.lo + c) * ldA + t.lo + r];
+        WB[c * GLD + r] = Bg[(size_t)(t.lo + c) * ldB + t.lo + r];
+        double const e = (r == c) ? 1.0 : 0.0;
+        UQ[c * GLD + r] = e; UZ[c * GLD + r] = e;
+    }
+    __syncthreads();
+
+    int const left = introduce ? 2 - 3 * nb : 0;
+    int const right = finalize ? n - 2 : t.right;
+    for (int begin = left; begin < right; begin++) {
+        // (1) left reflectors
+        if (tid < nb) {
+            int const i = tid, j = begin + 3 * i;
+            int len = 0;
+            double beta = 0.0, v1 = 0.0, v2 = 0.0, tau = 0.0;
+            if (j >= -1 && j < n - 2) {
+                if (j == -1) {
+                    double x[3];
+                    gep_shift_vector(WA, WB, sr[t.shift_off + 2 * i], si[t.shift_off + 2 * i],
+                        sr[t.shift_off + 2 * i + 1], si[t.shift_off + 2 * i + 1], x);
+                    len = 3;
+                    small_reflector(3, x, beta, v1, v2, tau);
+                } else {
+                    len = (j == n - 3) ? 2 : 3;
+                    double *col = WA + j * GLD + j + 1;
+                    small_reflector(len, col, beta, v1, v2, tau);
+                    col[0] = beta; col[1] = 0.0;
+                    if (len == 3) col[2] = 0.0;
+                }
+            }
+            R[6 * i + 0] = v1; R[6 * i + 1] = v2; R[6 * i + 2] = tau;
+            Ri[2 * i + 0] = j + 1; Ri[2 * i + 1] = len;
+        }
+        __syncthreads();
+        // (2) left: rows row0..row0+len-1 of A and B (columns >= row0); columns of Uq
+        for (int item = tid; item < nb * n * 3; item += GEP_CHASE_THREADS) {
+            int const i = item / (3 * n), rr = item - i * 3 * n;
+            int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
+            double const tau = R[6 * i + 2];
+            if (len == 0 || tau == 0.0) continue;
+            double const v1 = R[6 * i], v2 = R[6 * i + 1];
+            if (rr < 2 * n) {
+                int const c = rr < n ? rr : rr - n;
+                if (c < row0) continue;
+                double *p = (rr < n ? WA : WB) + c * GLD + row0;
+                double x0 = p[0], x1 = p[1], x2 = (len == 3) ? p[2] : 0.0;
+                double s = tau * (x0 + v1 * x1 + v2 * x2);
+                p[0] = x0 - s; p[1] = x1 - s * v1;
+                if (len == 3) p[2] = x2 - s * v2;
+            } else {
+                double *p = UQ + row0 * GLD + (rr - 2 * n);
+                double x0 = p[0], x1 = p[GLD], x2 = (len == 3) ? p[2 * GLD] : 0.0;
+                double s = tau * (x0 + v1 * x1 + v2 * x2);
+                p[0] = x0 - s; p[GLD] = x1 - s * v1;
+                if (len == 3) p[2 * GLD] = x2 - s * v2;
+            }
+        }
+        __syncthreads();
+        // (3) right reflectors: H e1 orthogonal to the rows of B that must become (0, *, *)
+        if (tid < nb) {
+            int const i = tid, len = Ri[2 * i + 1], row0 = Ri[2 * i];
+            double beta = 0.0, w1 = 0.0, w2 = 0.0, tauz = 0.0;
+            if (len == 3) {
+                double const *b = WB + row0 * GLD + row0;
+                double const p0 = b[1], p1 = b[GLD + 1], p2 = b[2 * GLD + 1];       // row row0+1
+                double const q0 = b[2], q1 = b[GLD + 2], q2 = b[2 * GLD + 2];       // row row0+2
+                // scale the rows first: the cross product of two tiny rows would underflow
+                double const mp = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
+                double const mq = fmax(fabs(q0), fmax(fabs(q1), fabs(q2)));
+                if (mp > 0.0 && mq > 0.0) {
+                    double const a0 = p0 / mp, a1 = p1 / mp, a2 = p2 / mp;
+                    double const c0 = q0 / mq, c1 = q1 / mq, c2 = q2 / mq;
+                    double x[3] = {a1 * c2 - a2 * c1, a2 * c0 - a0 * c2, a0 * c1 - a1 * c0};
+                    small_reflector(3, x, beta, w1, w2, tauz);
+                } else if (mp > 0.0) {
+                    // row row0+2 vanished: only row row0+1 constrains H e1 -- rotate in (0,1)
+                    double x[3] = {p1, -p0, 0.0};
+                    small_reflector(3, x, beta, w1, w2, tauz);
+                } else if (mq > 0.0) {
+                    double x[3] = {q1, -q0, 0.0};
+                    small_reflector(3, x, beta, w1, w2, tauz);
+                }
+            } else if (len == 2) {
+                double const *b = WB + row0 * GLD + row0;
+                double x[2] = {b[GLD + 1], -b[1]};
+                small_reflector(2, x, beta, w1, w2, tauz);
+            }
+            R[6 * i + 3] = w1; R[6 * i + 4] = w2; R[6 * i + 5] = tauz;
+        }
+        __syncthreads();
+        // (4) right: columns row0..row0+len-1; A rows 0..min(n-1,row0+3), B rows 0..row0+len-1,
+        //     all rows of Uz
+        for (int item = tid; item < nb * n * 3; item += GEP_CHASE_THREADS) {
+            int const i = item / (3 * n), rr = item - i * 3 * n;
+            int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
+            if (len == 0) continue;
+            double const w1 = R[6 * i + 3], w2 = R[6 * i + 4], tauz = R[6 * i + 5];
+            double *M; int r; bool clean = false;
+            if (rr < n) { r = rr; if (r > row0 + 3) continue; M = WA; }
+            else if (rr < 2 * n) { r = rr - n; if (r > row0 + len - 1) continue; M = WB; clean = r > row0; }
+            else { r = rr - 2 * n; M = UZ; }
+            double *p = M + row0 * GLD + r;
+            if (tauz != 0.0) {
+                double x0 = p[0], x1 = p[GLD], x2 = (len == 3) ? p[2 * GLD] : 0.0;
+                double s = tauz * (x0 + w1 * x1 + w2 * x2);
+                p[0] = x0 - s; p[GLD] = x1 - s * w1;
+                if (len == 3) p[2 * GLD] = x2 - s * w2;
+            }
+            if (clean) p[0] = 0.0;
+        }
+        __syncthreads();
+    }
+
+    double *Uo = Uout + (size_t)blockIdx.x * 2 * GWS * GWS;
+    for (int idx = tid; idx < n * n; idx += GEP_CHASE_THREADS) {
+        int r = idx % n, c = idx / n;
+        Ag[(size_t)(t.lo + c) * ldA + t.lo + r] = WA[c * GLD + r];
+        Bg[(size_t)(t.lo + c) * ldB + t.lo + r] = WB[c * GLD + r];
+        Uo[c * GWS + r] = UQ[c * GLD + r];
+        Uo[GWS * GWS + c * GWS + r] = UZ[c * GLD + r];
+    }
+}
+
+// Off-diagonal updates of all chains of one step, A and B in one launch.
+//   MODE 2 ("near"): X(win, next `adv` columns) <- Uq^T .      X in {A, B}
+//   MODE 0 ("far") : the remaining columns right of the window
+//   MODE 1         : X(above win, win) <- . Uz  (X in {A, B}),  Q(:, win) <- . Uq,  Z(:, win) <- . Uz
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void gep_update_kernel(SweepStep const step, double *__restrict__ A, int ldA,
+    double *__restrict__ B, int ldB, double *__restrict__ Q, int ldQ,
+    double *__restrict__ Z, int ldZ, int n, double const *__restrict__ U)
+{
+    int const k = blockIdx.y % step.ntasks, which = blockIdx.y / step.ntasks;
+    ChaseTask const t = make_task(step, k);
+    double const *Uq = U + (size_t)k * 2 * GWS * GWS, *Uz = Uq + GWS * GWS;
+    int const w = t.n, lo = t.lo;
+    if (MODE == 0 || MODE == 2) {
+        int const c0 = (MODE == 2) ? lo + w : lo + w + step.adv;
+        int ncols = n - c0;
+        if (MODE == 2) ncols = min(ncols, step.adv);
+        if ((int)blockIdx.x * 128 >= ncols) return;
+        int const ld = which ? ldB : ldA;
+        double *X = (which ? B : A) + (size_t)c0 * ld + lo;
+        gemm_tile<64, 128, 16, true, false>(w, ncols, w, 1.0, Uq, GWS, X, ld, 0.0, X, ld, 0, blockIdx.x);
+    } else {
+        // which: 0 = A, 1 = B, 2 = Z, 3 = Q   (Q/Z slots are launched only when present)
+        double *X; int ld, rows; double const *Uk = Uz;
+        if (which == 0) { X = A; ld = ldA; rows = lo; }
+        else if (which == 1) { X = B; ld = ldB; rows = lo; }
+        else if (which == 2 && Z) { X = Z; ld = ldZ; rows = n; }
+        else { X = Q; ld = ldQ; rows = n; Uk = Uq; }
+        if (X == nullptr || (int)blockIdx.x * 128 >= rows) return;
+        X += (size_t)lo * ld;
+        gemm_tile<128, 64, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, GWS, 0.0, X, ld, blockIdx.x, 0);
+    }
+}
+
+// sub[i] = A(i+1,i) for i in [0,hi-1); entries below the threshold become exact zeros
+__global__ void gep_scan_subdiag_kernel(int hi, double *__restrict__ A, int ldA, double thres,
+    double *__restrict__ sub)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hi - 1) return;
+    double *p = A + (size_t)i * ldA + i + 1;
+    double v = *p;
+    if (v != 0.0) {
+        bool small;
+        if (thres > 0.0) small = fabs(v) < thres;
+        else small = fabs(v) <= DBL_EPSILON * (fabs(A[(size_t)i * ldA + i]) + fabs(p[ldA]));
+        if (small) { v = 0.0; *p = 0.0; }
+    }
+    sub[i] = v;
+}
+
+__global__ void gep_set_entry_kernel(double *p, double v) { *p = v; }
+
+// ---- workspace --------------------------------------------------------------------------
+struct GepWorkspace {
+    int n = 0, nwmax = 0, max_chains = 0;
+    double *dU = nullptr;           // 2 (parity) x max_chains x {Uq, Uz} x GWS x GWS
+    double *dShiftR = nullptr, *dShiftI = nullptr, *dSub = nullptr;
+    double *dQl = nullptr, *dZl = nullptr, *dTmp = nullptr, *dAcc = nullptr;
+    double *hA = nullptr, *hB = nullptr, *hQ = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
+    bool attr_set = false;
+    hipStream_t far = nullptr;
+    static constexpr int EV_RING = 64;
+    hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
+
+    void release() {
+        void **dptrs[] = {(void **)&dU, (void **)&dShiftR, (void **)&dShiftI, (void **)&dSub,
+            (void **)&dQl, (void **)&dZl, (void **)&dTmp, (void **)&dAcc};
+        for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
+        void **hptrs[] = {(void **)&hA, (void **)&hB, (void **)&hQ, (void **)&hZ, (void **)&hSub};
+        for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
+        n = nwmax = max_chains = 0;
+    }
+    void ensure(int n_, int nw_, int chains_) {
+        if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
+        release();
+        n = n_; nwmax = nw_; max_chains = chains_;
+        size_t const w2 = (size_t)nwmax * nwmax * 8;
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * 2 * GWS * GWS * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dQl, w2));
+        SN_HIP_CHECK(hipMalloc((void **)&dZl, w2));
+        SN_HIP_CHECK(hipMalloc((void **)&dTmp, (size_t)n * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dAcc, 4 * 8));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hA, w2, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hB, w2, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hQ, w2, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hZ, w2, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
+        if (!attr_set) {
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_chase_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, GEP_CHASE_LDS_BYTES));
+            SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
+            for (int k = 0; k < EV_RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&far_done[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_update_kernel<2>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, GEP_LDS_BYTES_L));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_update_kernel<0>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, GEP_LDS_BYTES_L));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_update_kernel<1>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, GEP_LDS_BYTES_R));
+            attr_set = true;
+        }
+    }
+};
+static GepWorkspace g_gws;
+void gep_schur_release_workspace() { g_gws.release(); }
+
+namespace {
+
+static inline double wall()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct GepDriver {
+    hipStream_t s;
+    int n; double *A; int ldA; double *B; int ldB; double *Q; int ldQ; double *Z; int ldZ;
+    GepWorkspace &ws;
+    SchurStats st;
+
+    // X <- op applied in place through the scratch panel for windows wider than one GEMM tile
+    void left_update(double *X, int ld, int lo, int w, double const *dU, int ldu)
+    {
+        int const cols = n - (lo + w);
+        if (cols <= 0) return;
+        double *P = X + (size_t)(lo + w) * ld + lo;
+        if (w <= 128) dgemm_left_inplace(s, w, cols, dU, ldu, P, ld);
+        else {
+            dgemm(s, 'T', 'N', w, cols, w, 1.0, dU, ldu, P, ld, 0.0, ws.dTmp, w);
+            copy_matrix(s, w, cols, ws.dTmp, w, P, ld);
+        }
+    }
+    void right_update(double *X, int ld, int rows, int lo, int w, double const *dU, int ldu)
+    {
+        if (rows <= 0) return;
+        double *P = X + (size_t)lo * ld;
+        if (w <= 128) dgemm_right_inplace(s, rows, w, dU, ldu, P, ld);
+        else {
+            dgemm(s, 'N', 'N', rows, w, w, 1.0, P, ld, dU, ldu, 0.0, ws.dTmp, rows);
+            copy_matrix(s, rows, w, ws.dTmp, rows, P, ld);
+        }
+    }
+    // (A,B)(win, right) <- Ql^T .,  (A,B)(above, win) <- . Zl,  Q(:,win) <- . Ql,  Z(:,win) <- . Zl
+    void apply_transform(int lo, int w, double const *dQl, double const *dZl, int ldu)
+    {
+        left_update(A, ldA, lo, w, dQl, ldu);
+        left_update(B, ldB, lo, w, dQl, ldu);
+        right_update(A, ldA, lo, lo, w, dZl, ldu);
+        right_update(B, ldB, lo, lo, w, dZl, ldu);
+        if (Q) right_update(Q, ldQ, n, lo, w, dQl, ldu);
+        if (Z) right_update(Z, ldZ, n, lo, w, dZl, ldu);
+        st.gemm_flops += 2.0 * w * w * (2.0 * (n - lo - w) + 2.0 * lo + (Q ? n : 0) + (Z ? n : 0));
+    }
+
+    void download_windows(int lo, int w)
+    {
+        double t0 = wall();
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hA, (size_t)w * 8, A + (size_t)lo * ldA + lo, (size_t)ldA * 8,
+            (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hB, (size_t)w * 8, B + (size_t)lo * ldB + lo, (size_t)ldB * 8,
+            (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        st.wait_s += wall() - t0;
+    }
+    void upload_windows(int lo, int w)
+    {
+        SN_HIP_CHECK(hipMemcpy2DAsync(A + (size_t)lo * ldA + lo, (size_t)ldA * 8, ws.hA, (size_t)w * 8,
+            (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(B + (size_t)lo * ldB + lo, (size_t)ldB * 8, ws.hB, (size_t)w * 8,
+            (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dQl, ws.hQ, (size_t)w * w * 8, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dZl, ws.hZ, (size_t)w * w * 8, hipMemcpyHostToDevice, s));
+    }
+
+    // small pencil on a host copy (row S6, GEP branch: schur/cpu_utils.c:3185-3371)
+    int small_block(int lo, int w, double *real, double *imag, double *beta)
+    {
+        download_windows(lo, w);
+        for (int j = 0; j < w; j++)
+            for (int i = 0; i < w; i++) ws.hQ[(size_t)j * w + i] = ws.hZ[(size_t)j * w + i] = (i == j) ? 1.0 : 0.0;
+        std::vector<double> ar(w), ai(w), be(w);
+        int info = host::gep_small_schur(w, ws.hA, w, ws.hB, w, ws.hQ, w, ws.hZ, w, w, ar.data(), ai.data(), be.data());
+        if (info != 0) return info;
+        upload_windows(lo, w);
+        apply_transform(lo, w, ws.dQl, ws.dZl, w);
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        if (real) for (int i = 0; i < w; i++) { real[lo + i] = ar[i]; imag[lo + i] = ai[i]; beta[lo + i] = be[i]; }
+        st.small_solves++;
+        return 0;
+    }
+
+    // one multi-shift QZ sweep over the active block [ilo, ihi); same schedule as schur.hip
+    void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
+    {
+        int const size = ihi - ilo;
+        int const nbulges = nshifts / 2;
+        int const ws_ = std::min(GWS, size);
+        int nbc = std::min(GNB, (ws_ - 1) / 6);
+        if (nbc < 1) nbc = 1;
+        if (size <= GWS) nbc = std::min(nbulges, std::max(1, (size - 1) / 3));
+        nbc = std::min(nbc, GNB);
+        int const chains = divceil(nbulges, nbc);
+        int const adv = ws_ - 1 - 3 * nbc;
+        int const gap = (adv > 0) ? divceil(ws_ + adv, adv) : 1;
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftR, sr, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftI, si, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
+        int const steps_per_chain = (size <= GWS) ? 1 : divceil(size - ws_, adv) + 1;
+        int const total_steps = steps_per_chain + (chains - 1) * gap;
+        SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
+        hipStream_t const f = ws.far;
+        long issued = 0;
+        int last_t = -2;
+        int const qz = (Q ? 1 : 0) + (Z ? 1 : 0);
+        for (int t = 0; t < total_steps; t++) {
+            int cmin = (t - steps_per_chain + 1 + gap - 1) / gap;
+            if (t - steps_per_chain + 1 <= 0) cmin = 0;
+            int const cmax = std::min(chains - 1, t / gap);
+            if (cmax < cmin) continue;
+            step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
+            int const ntasks = step.ntasks;
+            int const par = (int)(issued & 1);
+            double *Ubuf = ws.dU + (size_t)par * ws.max_chains * 2 * GWS * GWS;
+            int const ev = (int)(issued % GepWorkspace::EV_RING);
+            int const evp = (int)((issued + GepWorkspace::EV_RING - 1) % GepWorkspace::EV_RING);
+            // see schur.hip (and tests/test_schur_pipeline.py) for the two wait rules
+            if (issued > 0 && last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            hipLaunchKernelGGL(gep_chase_kernel, dim3(ntasks), dim3(GEP_CHASE_THREADS), GEP_CHASE_LDS_BYTES, s,
+                step, A, ldA, B, ldB, Ubuf, ws.dShiftR, ws.dShiftI);
+            st.chase_launches++;
+            int max_far = 0;
+            for (int k = 0; k < ntasks; k++) {
+                ChaseTask const tk = make_task(step, k);
+                int const rc = n - (tk.lo + tk.n);
+                max_far = std::max(max_far, rc - adv);
+                st.gemm_flops += 2.0 * tk.n * tk.n * (2.0 * rc + 2.0 * tk.lo + (double)qz * n);
+            }
+            if (issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            hipLaunchKernelGGL(gep_update_kernel<2>, dim3(1, 2 * ntasks), dim3(256), GEP_LDS_BYTES_L, s,
+                step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
+            SN_HIP_CHECK(hipEventRecord(ws.near_done[ev], s));
+            SN_HIP_CHECK(hipStreamWaitEvent(f, ws.near_done[ev], 0));
+            if (max_far > 0)
+                hipLaunchKernelGGL(gep_update_kernel<0>, dim3(divceil(max_far, 128), 2 * ntasks), dim3(256),
+                    GEP_LDS_BYTES_L, f, step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
+            hipLaunchKernelGGL(gep_update_kernel<1>, dim3(divceil(n, 128), (2 + qz) * ntasks), dim3(256),
+                GEP_LDS_BYTES_R, f, step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
+            SN_HIP_CHECK(hipEventRecord(ws.far_done[ev], f));
+            issued++;
+            last_t = t;
+        }
+        if (issued > 0)
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((issued - 1) % GepWorkspace::EV_RING)], 0));
+        st.sweeps++;
+    }
+};
+
+} // namespace
+
+int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB, int ldB,
+    double *dQ, int ldQ, double *dZ, int ldZ, double *real, double *imag, double *beta,
+    SchurParams const &prm, SchurStats *stats)
+{
+    static hipStream_t own = nullptr;
+    static hipEvent_t fence = nullptr;
+    if (!own) {
+        SN_HIP_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+        SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
+    }
+    hipStream_t s = own;
+    SN_HIP_CHECK(hipEventRecord(fence, caller));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, fence, 0));
+
+    // parameters: the host QZ kernels cost about 3x the standard ones per window row, so the
+    // AED window / shift count defaults are smaller than in schur.hip
+    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 768) : std::min(160, std::max(16, n / 8));
+    int ns_conf = prm.shift_count > 0 ? prm.shift_count : std::min(100, std::max(2, 2 * nw_conf / 3));
+    ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
+    ns_conf = std::max(2, ns_conf - ns_conf % 2);
+    int const small_limit = prm.small_limit > 0 ? std::min(prm.small_limit, 768)
+                                                : std::max(GWS + 32, std::min(200, nw_conf));
+    int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 40;
+    int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
+
+    GepWorkspace &ws = g_gws;
+    int const wmax = std::max({nw_conf + nw_conf / 2 + 8, small_limit, 2 * GWS});
+    ws.ensure(n, wmax, ns_conf / 2 + 1);
+    GepDriver d{s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, ws, SchurStats{}};
+    // the update kernel identifies "no Q" by a null pointer but still needs distinct slots
+    hipEvent_t e0, e1;
+    SN_HIP_CHECK(hipEventCreate(&e0)); SN_HIP_CHECK(hipEventCreate(&e1));
+    SN_HIP_CHECK(hipEventRecord(e0, s));
+
+    // deflation threshold for A's sub-diagonal / AED spike: u*||A||_F (schur/core.c:2390-2436)
+    double thres = prm.threshold;
+    if (thres == -1.0 || thres == -2.0) {
+        double h = 0.0;
+        SN_HIP_CHECK(hipMemsetAsync(ws.dAcc, 0, 8, s));
+        sumsq_diff(s, n, n, dA, ldA, nullptr, 0, 0.0, ws.dAcc);
+        SN_HIP_CHECK(hipMemcpyAsync(&h, ws.dAcc, 8, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        thres = DBL_EPSILON * std::sqrt(h);
+    } else if (thres == -3.0) thres = 0.0;
+    else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
+
+    std::vector<double> sr(wmax), si(wmax), spike(wmax);
+    int rc = STARNEIG_SUCCESS;
+    int ihi = n, iter = 0, stagnation = 0;
+    while (ihi > 0) {
+        hipLaunchKernelGGL(gep_scan_subdiag_kernel, dim3(divceil(std::max(ihi - 1, 1), 256)), dim3(256),
+            0, s, ihi, dA, ldA, thres, ws.dSub);
+        if (ihi > 1) {
+            double tw = wall();
+            SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            d.st.wait_s += wall() - tw;
+        }
+        int ilo = ihi - 1;
+        while (ilo > 0 && ws.hSub[ilo - 1] != 0.0) ilo--;
+        int const size = ihi - ilo;
+        if (size <= small_limit) {
+            int info = d.small_block(ilo, size, real, imag, beta);
+            if (info != 0) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+            ihi = ilo; stagnation = 0; continue;
+        }
+        if (iter >= iter_limit * std::max(1, n / std::max(1, ns_conf))) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+
+        // ---- aggressive early deflation on the trailing window ---------------------------------
+        int nw = std::min(nw_conf, size);
+        if (stagnation > 0) nw = std::min(size, std::min(wmax, nw + nw / 20 * stagnation + 2));
+        int const kw = ihi - nw;
+        double const sub = (kw > ilo) ? ws.hSub[kw - 1] : 0.0;
+        d.download_windows(kw, nw);
+        double t_aed0 = wall();
+        host::AedResult ar = host::gep_aed_window(nw, ws.hA, nw, ws.hB, nw, ws.hQ, nw, ws.hZ, nw, sub, thres,
+            spike.data(), sr.data(), si.data());
+        d.st.aed_host_s += wall() - t_aed0;
+        d.st.aeds++;
+        if (ar.failed) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+        if (ar.deflated > 0) {
+            d.upload_windows(kw, nw);
+            if (kw > ilo)
+                hipLaunchKernelGGL(gep_set_entry_kernel, dim3(1), dim3(1), 0, s,
+                    dA + (size_t)(kw - 1) * ldA + kw, spike[0]);
+            d.apply_transform(kw, nw, ws.dQl, ws.dZl, nw);
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            if (real) {
+                int const off = nw - ar.deflated;
+                host::gep_extract_eigenvalues(ar.deflated, ws.hA + (size_t)off * nw + off, nw,
+                    ws.hB + (size_t)off * nw + off, nw, real + ihi - ar.deflated, imag + ihi - ar.deflated,
+                    beta + ihi - ar.deflated);
+            }
+            ihi -= ar.deflated;
+            stagnation = 0;
+        } else stagnation++;
+        if (ihi - ilo <= small_limit) continue;
+        if (100 * ar.deflated > nibble * nw) continue;
+        int nshifts = std::min(ar.shifts, ns_conf);
+        nshifts -= nshifts % 2;
+        // exceptional shifts (cf. schur.hip) on the eigenvalue scale a_ii / b_ii
+        if (nshifts < 2 || (stagnation > 0 && stagnation % 6 == 0)) {
+            int const want = std::max(2, std::min(ns_conf, (ihi - ilo - 2) / 2 * 2));
+            int const first = ihi - (want + 2) >= 0 ? ihi - (want + 2) : 0;
+            int const cnt = ihi - first;
+            std::vector<double> da(cnt), db(cnt);
+            SN_HIP_CHECK(hipMemcpy2DAsync(da.data(), 8, dA + (size_t)first * ldA + first, (size_t)(ldA + 1) * 8,
+                8, cnt, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipMemcpy2DAsync(db.data(), 8, dB + (size_t)first * ldB + first, (size_t)(ldB + 1) * 8,
+                8, cnt, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            nshifts = 0;
+            for (int i = ihi - 1; i >= ilo + 2 && nshifts + 2 <= want; i -= 2) {
+                double const bi = db[i - first] != 0.0 ? db[i - first] : 1.0;
+                double const bm = db[i - 1 - first] != 0.0 ? std::fabs(db[i - 1 - first]) : 1.0;
+                double ss = (std::fabs(ws.hSub[i - 1]) + std::fabs(ws.hSub[i - 2])) / bm;
+                double const h = da[i - first] / bi;
+                double aa = 0.75 * ss + h, bb = ss, cc = -0.4375 * ss, dd = aa, cs, sn;
+                host::lanv2(aa, bb, cc, dd, sr[nshifts], si[nshifts], sr[nshifts + 1], si[nshifts + 1], cs, sn);
+                if (ss == 0.0) { sr[nshifts] = sr[nshifts + 1] = h + 1e-3 * (1.0 + std::fabs(h)); si[nshifts] = si[nshifts + 1] = 0.0; }
+                nshifts += 2;
+            }
+            if (nshifts < 2) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+        }
+        if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+
+        d.sweep(ilo, ihi, nshifts, sr.data(), si.data());
+        iter++;
+    }
+    SN_HIP_CHECK(hipEventRecord(e1, s));
+    SN_HIP_CHECK(hipStreamWaitEvent(caller, e1, 0));
+    SN_HIP_CHECK(hipEventSynchronize(e1));
+    SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
+    SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
+    if (stats) *stats = d.st;
+    return rc;
+}
+
+} // namespace sn

@@ -1,6 +1,7 @@
 // Small device helpers: copies, fills, the reference test driver's LCG inputs,
 // and the Frobenius-norm pieces of the acceptance checks.
 #include "common.h"
+#include <algorithm>
 
 namespace sn {
 
@@ -79,6 +80,49 @@ void lcg_fill(hipStream_t s, int m, int n, unsigned seed, int mode, double *A, i
     unsigned long long threads = (total + LCG_RUN - 1) / LCG_RUN;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(lcg_fill_kernel, dim3(blocks), dim3(256), 0, s, m, n, seed, mode, A, lda);
+}
+
+// Column c of a structured LCG matrix holds cnt(c) = min(m, c + extra) draws (extra = 2:
+// upper Hessenberg, 1: upper triangular; test/common/init.c:122-138,159-175), the rest of
+// the column is zero.  One workgroup per column; `skip` draws precede the matrix.
+__global__ void lcg_structured_kernel(int m, int n, unsigned seed, unsigned long long skip,
+    int extra, double *__restrict__ A, int lda)
+{
+    int const c = blockIdx.x;
+    // draws before column c: sum_{k<c} min(m, k + extra)
+    long long const f = m - extra > 0 ? m - extra : 0;    // columns 0..f-1 hold fewer than m draws
+    long long const cc = c < f ? c : f;
+    unsigned long long const before =
+        (unsigned long long)(cc * (cc - 1) / 2 + cc * extra + ((long long)c - cc) * m);
+    int const cnt = min(m, c + extra);
+    for (int r0 = threadIdx.x * LCG_RUN; r0 < m; r0 += blockDim.x * LCG_RUN) {
+        int const rend = min(m, r0 + LCG_RUN);
+        if (r0 < cnt) {
+            unsigned x = lcg_jump(seed & 0x7fffffffu, skip + before + r0);
+            for (int r = r0; r < rend; r++) {
+                if (r < cnt) {
+                    x = (x * 1103515245u + 12345u) & 0x7fffffffu;
+                    A[(size_t)c * lda + r] = 2.0 * ((double)x / 2147483647.0) - 1.0;
+                } else A[(size_t)c * lda + r] = 0.0;
+            }
+        } else
+            for (int r = r0; r < rend; r++) A[(size_t)c * lda + r] = 0.0;
+    }
+}
+
+static unsigned long long structured_draws(int m, int n, int extra)
+{
+    unsigned long long t = 0;
+    for (int c = 0; c < n; c++) t += (unsigned long long)std::min(m, c + extra);
+    return t;
+}
+
+void lcg_pencil(hipStream_t s, int n, unsigned seed, double *H, int ldh, double *R, int ldr)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lcg_structured_kernel, dim3(n), dim3(256), 0, s, n, n, seed, 0ull, 2, H, ldh);
+    hipLaunchKernelGGL(lcg_structured_kernel, dim3(n), dim3(256), 0, s, n, n, seed,
+        structured_draws(n, n, 2), 1, R, ldr);
 }
 
 // acc[0] += sum (X - sub*Y)^2 (+ diag shift), acc[1] += count of nonzeros below sub-diagonal

@@ -67,6 +67,18 @@ SIGNATURES = {
     "starneig_SEP_SM_Reduce": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "starneig_SEP_SM_Select": (C.c_int, [C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "starneig_GEP_SM_Schur": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    "starneig_GEP_SM_Schur_expert": (
+        C.c_int, [C.POINTER(SchurConf), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp,
+                  C.c_int, _vp, _vp, _vp]),
+    "starneig_amd_gep_schur_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
+                  C.POINTER(SchurConf), _vp, _dp]),
+    "starneig_amd_lcg_pencil_device": (
+        C.c_int, [C.c_int, C.c_uint, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "starneig_amd_check_pencil_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _dp, _vp]),
     "starneig_amd_schur_device": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
@@ -170,6 +182,25 @@ def SEP_SM_Schur_expert(conf, n, H, ldH, Q, ldQ, real, imag):
         None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data)
 
 
+def _arr_ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def GEP_SM_Schur(n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta):
+    """reference gep_sm.h:164-170; eigenvalues are (real + i imag) / beta."""
+    return load().starneig_GEP_SM_Schur(
+        n, _host_ptr(H), ldH, _host_ptr(R), ldR, _host_ptr(Q), ldQ, _host_ptr(Z), ldZ,
+        _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta))
+
+
+def GEP_SM_Schur_expert(conf, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta):
+    """reference gep_sm.h:503-510."""
+    cp = C.byref(conf) if conf is not None else None
+    return load().starneig_GEP_SM_Schur_expert(
+        cp, n, _host_ptr(H), ldH, _host_ptr(R), ldR, _host_ptr(Q), ldQ, _host_ptr(Z), ldZ,
+        _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta))
+
+
 def SEP_SM_Reduce(n, A, ldA, Q, ldQ, real, imag):
     """reference sep_sm.h (Reduce) without predicate/selection."""
     return load().starneig_SEP_SM_Reduce(
@@ -266,6 +297,45 @@ def schur_device(tH, tQ, n=None, conf=None, eigenvalues=True):
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
              "aed_host_s": st[6], "gpu_wait_s": st[7]}
     return rc, real, imag, stats
+
+
+def gep_schur_device(tH, tR, tQ, tZ, n=None, conf=None, eigenvalues=True):
+    """Returns (rc, real, imag, beta, stats)."""
+    n = tH.shape[0] if n is None else n
+    real = np.zeros(n) if eigenvalues else None
+    imag = np.zeros(n) if eigenvalues else None
+    beta = np.zeros(n) if eigenvalues else None
+    st = (C.c_double * 8)()
+    rc = load().starneig_amd_gep_schur_device(
+        n, _dev_ptr(tH), tH.shape[1], _dev_ptr(tR), tR.shape[1],
+        _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0,
+        _dev_ptr(tZ), tZ.shape[1] if tZ is not None else 0,
+        _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta),
+        C.byref(conf) if conf is not None else None, _stream_ptr(), st)
+    stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
+             "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
+             "aed_host_s": st[6], "gpu_wait_s": st[7]}
+    return rc, real, imag, beta, stats
+
+
+def lcg_pencil_device(tH, tR, n, seed=2019):
+    return load().starneig_amd_lcg_pencil_device(
+        n, seed, _dev_ptr(tH), tH.shape[1], _dev_ptr(tR), tR.shape[1], _stream_ptr())
+
+
+def check_pencil_device(tQ, tS, tZ, tA0, n=None):
+    """2^52 ||Q S Z^T - A0|| / ||A0||, orthogonality of Q and Z (in u), non-zeros of S below
+    the first sub-diagonal -- on the GPU."""
+    import torch
+    n = tA0.shape[0] if n is None else n
+    w1 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    w2 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    out = (C.c_double * 4)()
+    rc = load().starneig_amd_check_pencil_device(
+        n, _dev_ptr(tQ), tQ.shape[1], _dev_ptr(tS), tS.shape[1], _dev_ptr(tZ), tZ.shape[1],
+        _dev_ptr(tA0), tA0.shape[1], _dev_ptr(w1), _dev_ptr(w2), out, _stream_ptr())
+    return rc, {"residual_u": out[0], "orthogonality_q_u": out[1], "orthogonality_z_u": out[2],
+                "below_subdiagonal": int(out[3])}
 
 
 def dgemm_device(transA, transB, m, n, k, alpha, tA, ldA, tB, ldB, beta, tC, ldC):

@@ -1,0 +1,161 @@
+"""GPU parity tests of the generalized Schur (QZ) leg -- BASELINE config 5: the HIP multi-shift
+QZ path through the C-ABI (starneig_GEP_SM_Schur and its device-pointer twin) against the CPU
+oracle (oracle/gep_oracle.c), the committed LAPACK golden eigenvalues and the reference's
+acceptance checks (test/common/checks.c residuals, hooks.c Schur-form structure).
+
+Generalized Schur forms are not unique, so parity is on invariants.  Tolerances in u = 2^-52:
+residuals / orthogonality < 500 u (the reference's warn threshold); eigenvalues against the
+oracle and against the LAPACK golden vectors within max(1e4 u, 20 x lapack_spread_u), where
+lapack_spread_u (stored in the fixture) is the distance between LAPACK's own real and complex
+QZ answers for that pencil -- the eigenvalues of these pencils are ill conditioned."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from helpers import U, WARN_U, to_device, to_host
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def check_pencil(H0, R0, S, T, Q, Z, ar, ai, be):
+    n = H0.shape[1]
+    assert O.check_gep_schur_form(S, T) == 0
+    assert O.pencil_residual_u(Q, S, Z, H0) < WARN_U
+    assert O.pencil_residual_u(Q, T, Z, R0) < WARN_U
+    assert O.orthogonality_u(Q) < WARN_U and O.orthogonality_u(Z) < WARN_U
+    # returned eigenvalues == eigenvalues of the diagonal blocks
+    er, ei, eb = O.gep_extract_eigenvalues(S, T)
+    assert O.match_eigenvalues((ar + 1j * ai) / be, (er + 1j * ei) / eb) < 1e3
+    assert np.all(be >= 0.0)
+    k = 0
+    while k < n:
+        if ai[k] != 0.0:
+            assert ai[k] > 0.0 and ai[k + 1] < 0.0 and S[k + 1, k] != 0.0
+            k += 2
+        else:
+            assert k + 1 >= n or S[k + 1, k] == 0.0
+            k += 1
+
+
+def run_host(node, H0, R0, conf=None):
+    n = H0.shape[1]
+    H, R = H0.copy(order="F"), R0.copy(order="F")
+    Q, Z = O.identity(n, ld=H.shape[0]), O.identity(n, ld=H.shape[0])
+    ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+    if conf is None:
+        rc = node.GEP_SM_Schur(n, H, H.shape[0], R, R.shape[0], Q, Q.shape[0], Z, Z.shape[0], ar, ai, be)
+    else:
+        rc = node.GEP_SM_Schur_expert(conf, n, H, H.shape[0], R, R.shape[0], Q, Q.shape[0], Z, Z.shape[0],
+                                      ar, ai, be)
+    assert rc == 0
+    return H, R, Q, Z, ar, ai, be
+
+
+@pytest.mark.parametrize("kind", ["lcg2019", "wellcond2019"])
+@pytest.mark.parametrize("n", [48, 150, 400])
+def test_qz_against_oracle_and_lapack_golden(node, kind, n):
+    g = np.load(os.path.join(GOLD, f"gep_{kind}_n{n}.npz"))
+    H0, R0 = O.random_pencil(n) if kind == "lcg2019" else O.random_pencil_wellcond(n)
+    S, T, Q, Z, ar, ai, be = run_host(node, H0, R0)
+    check_pencil(H0, R0, S, T, Q, Z, ar, ai, be)
+    ev = (ar + 1j * ai) / be
+    tol = max(1e4, 20.0 * float(g["lapack_spread_u"]))
+    assert O.match_eigenvalues(ev, g["eig_real"] + 1j * g["eig_imag"]) < tol
+    Ho, Ro = H0.copy(order="F"), R0.copy(order="F")
+    info, oar, oai, obe = O.gep_schur(Ho, Ro, O.identity(n, ld=Ho.shape[0]), O.identity(n, ld=Ho.shape[0]))
+    assert info == 0
+    assert O.match_eigenvalues(ev, (oar + 1j * oai) / obe) < tol
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 63, 64, 65, 97, 129, 257, 700, 1500])
+def test_qz_sizes(node, n):
+    """edge sizes around the 64-row LDS window, the small-block limit and several chains"""
+    H0, R0 = O.random_pencil_wellcond(n, seed=11 + n)
+    S, T, Q, Z, ar, ai, be = run_host(node, H0, R0)
+    check_pencil(H0, R0, S, T, Q, Z, ar, ai, be)
+    if n <= 700:
+        Ho, Ro = H0.copy(order="F"), R0.copy(order="F")
+        info, oar, oai, obe = O.gep_schur(Ho, Ro, O.identity(n, ld=Ho.shape[0]), O.identity(n, ld=Ho.shape[0]))
+        assert info == 0
+        # conditioning-aware: LAPACK's own spread on these pencils is up to ~3e4 u at n = 400
+        assert O.match_eigenvalues((ar + 1j * ai) / be, (oar + 1j * oai) / obe) < 2e6
+
+
+@pytest.mark.parametrize("aed,shifts,small", [(40, 20, 96), (96, 60, 128), (200, 120, 150), (24, 8, 100)])
+def test_qz_expert_configurations(node, aed, shifts, small):
+    n = 600
+    H0, R0 = O.random_pencil_wellcond(n, seed=5)
+    conf = node.schur_init_conf()
+    conf.aed_window_size = aed; conf.shift_count = shifts; conf.small_limit = small
+    S, T, Q, Z, ar, ai, be = run_host(node, H0, R0, conf)
+    check_pencil(H0, R0, S, T, Q, Z, ar, ai, be)
+
+
+def test_qz_nontrivial_q_and_z(node):
+    """Q and Z are updated from the right: start from random orthogonal factors"""
+    n = 300
+    H0, R0 = O.random_pencil_wellcond(n, seed=3)
+    rng = np.random.default_rng(0)
+    Q0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, n)))[0])
+    Z0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, n)))[0])
+    H, R, Q, Z = H0[:n].copy(order="F"), R0[:n].copy(order="F"), Q0.copy(order="F"), Z0.copy(order="F")
+    ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+    assert node.GEP_SM_Schur(n, H, n, R, n, Q, n, Z, n, ar, ai, be) == 0
+    A0 = Q0 @ H0[:n] @ Z0.T
+    B0 = Q0 @ R0[:n] @ Z0.T
+    assert np.linalg.norm(Q @ H @ Z.T - A0) / np.linalg.norm(A0) < WARN_U * U
+    assert np.linalg.norm(Q @ R @ Z.T - B0) / np.linalg.norm(B0) < WARN_U * U
+    assert O.check_gep_schur_form(H, R) == 0
+
+
+def test_qz_argument_errors(node):
+    n = 8
+    H0, R0 = O.random_pencil(n)
+    Q, Z = O.identity(n), O.identity(n)
+    v = np.zeros(n)
+    ld = H0.shape[0]
+    assert node.GEP_SM_Schur(0, H0, ld, R0, ld, Q, ld, Z, ld, v, v, v) == -1
+    assert node.GEP_SM_Schur(n, None, ld, R0, ld, Q, ld, Z, ld, v, v, v) == -2
+    assert node.GEP_SM_Schur(n, H0, n - 1, R0, ld, Q, ld, Z, ld, v, v, v) == -3
+    assert node.GEP_SM_Schur(n, H0, ld, None, ld, Q, ld, Z, ld, v, v, v) == -4
+    assert node.GEP_SM_Schur(n, H0, ld, R0, n - 1, Q, ld, Z, ld, v, v, v) == -5
+    assert node.GEP_SM_Schur(n, H0, ld, R0, ld, None, ld, Z, ld, v, v, v) == -6
+    assert node.GEP_SM_Schur(n, H0, ld, R0, ld, Q, ld, None, ld, v, v, v) == -8
+    assert node.GEP_SM_Schur(n, H0, ld, R0, ld, Q, ld, Z, ld, None, v, v) == -10
+
+
+def test_qz_device_pencil_generator_bit_exact(node):
+    """the in-HBM LCG pencil generator equals the oracle's (reference init.c) bit for bit"""
+    for n in (5, 64, 333):
+        tH, tR = node.device_matrix(n), node.device_matrix(n)
+        assert node.lcg_pencil_device(tH, tR, n, seed=2019) == 0
+        H, R = O.random_pencil(n, ld=tH.shape[1])
+        assert np.array_equal(to_host(tH), H) and np.array_equal(to_host(tR), R)
+
+
+@pytest.mark.parametrize("n", [3000])
+def test_qz_device_resident_lcg_pencil(node, n):
+    """BASELINE config 5 shape at a size the suite affords: device-resident LCG pencil, Q = Z = I,
+    acceptance checks computed on the GPU"""
+    import torch
+    tH, tR = node.device_matrix(n), node.device_matrix(n)
+    assert node.lcg_pencil_device(tH, tR, n, seed=2019) == 0
+    tH0, tR0 = tH.clone(), tR.clone()
+    tQ, tZ = node.device_matrix(n), node.device_matrix(n)
+    node.set_matrix_device(tQ, n, n, 0.0, 1.0); node.set_matrix_device(tZ, n, n, 0.0, 1.0)
+    rc, ar, ai, be, st = node.gep_schur_device(tH, tR, tQ, tZ, n=n)
+    assert rc == 0
+    torch.cuda.synchronize()
+    rc, ca = node.check_pencil_device(tQ, tH, tZ, tH0, n=n)
+    assert rc == 0
+    rc, cb = node.check_pencil_device(tQ, tR, tZ, tR0, n=n)
+    assert rc == 0
+    assert ca["residual_u"] < WARN_U and cb["residual_u"] < WARN_U
+    assert ca["orthogonality_q_u"] < WARN_U and ca["orthogonality_z_u"] < WARN_U
+    assert ca["below_subdiagonal"] == 0
+    S, T = to_host(tH), to_host(tR)
+    assert O.check_gep_schur_form(S, T) == 0
+    assert st["sweeps"] > 0 and st["aeds"] > 0
