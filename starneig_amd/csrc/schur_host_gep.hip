@@ -325,7 +325,18 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
     int i = nw - 1, nd = 0;
     while (i >= 0) {
         bool two = (i >= 1 && A(i, i - 1) != 0.0);
-        bool ok = std::fabs(spike[i]) < thres && (!two || std::fabs(spike[i - 1]) < thres);
+        bool ok;
+        if (thres > 0.0)        // norm-stable criterion (cpu_utils.c:2891-2931)
+            ok = std::fabs(spike[i]) < thres && (!two || std::fabs(spike[i - 1]) < thres);
+        else {                  // LAPACK-style criterion (:2937-2988)
+            double const ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)nw / ulp);
+            double foo = std::fabs(A(i, i));
+            if (two) foo += std::sqrt(std::fabs(A(i, i - 1))) * std::sqrt(std::fabs(A(i - 1, i)));
+            if (foo == 0.0) foo = std::fabs(sub);
+            double sp = std::fabs(spike[i]);
+            if (two) sp = std::max(sp, std::fabs(spike[i - 1]));
+            ok = sp < std::max(smlnum, ulp * foo);
+        }
         if (!ok) break;
         nd += two ? 2 : 1; i -= two ? 2 : 1;
     }
