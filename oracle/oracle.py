@@ -24,9 +24,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(so):
-            build()
+        so = build()        # rebuilds only when a source is newer than the library
         L = C.CDLL(so)
         dp = C.POINTER(C.c_double)
         L.oracle_init_prand.argtypes = [C.c_uint]

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cfloat>
 #include <chrono>
+#include <cstdlib>
 #include <starneig/error.h>
 
 namespace sn {
@@ -242,15 +243,15 @@ struct SchurWorkspace {
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
         SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * WS_MAX * WS_MAX * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)nwmax * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dWin, (size_t)nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dZ, (size_t)nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmp, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dAcc, 4 * 8));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)nwmax * nwmax * 8, hipHostMallocDefault));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)nwmax * nwmax * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
@@ -343,21 +344,27 @@ struct Driver {
         SN_HIP_CHECK(hipMemcpy2DAsync(H + (size_t)lo * ldH + lo, (size_t)ldH * 8, h, (size_t)ldh * 8,
             (size_t)w * 8, w, hipMemcpyHostToDevice, s));
     }
-    void upload_matrix(double *d, double const *h, int w)
+    void upload_matrix(double *d, double const *h, int ldh, int w)
     {
-        SN_HIP_CHECK(hipMemcpyAsync(d, h, (size_t)w * w * 8, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(d, (size_t)w * 8, h, (size_t)ldh * 8, (size_t)w * 8, w,
+            hipMemcpyHostToDevice, s));
     }
+    // host copies of a window use a padded leading dimension: w*8 bytes is a multiple of 512 for
+    // the usual window sizes and the row walks of the sequential kernels would hit a handful
+    // of cache sets (measured: 1.5x on the AED kernel at w = 192)
+    static int host_ld(int w) { return w + 8; }
 
     // small dense Schur problem on a host copy (row S6; schur/cpu.c:402-496)
     int small_block(int lo, int w, double *real, double *imag)
     {
-        download_window(lo, w, ws.hWin, w);
-        for (int j = 0; j < w; j++) for (int i = 0; i < w; i++) ws.hZ[(size_t)j * w + i] = (i == j) ? 1.0 : 0.0;
+        int const ldh = host_ld(w);
+        download_window(lo, w, ws.hWin, ldh);
+        for (int j = 0; j < w; j++) for (int i = 0; i < w; i++) ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
         std::vector<double> wr(w), wi(w);
-        int info = host::small_schur(w, ws.hWin, w, ws.hZ, w, wr.data(), wi.data());
+        int info = host::small_schur(w, ws.hWin, ldh, ws.hZ, ldh, wr.data(), wi.data());
         if (info != 0) return info;
-        upload_window(lo, w, ws.hWin, w);
-        upload_matrix(ws.dZ, ws.hZ, w);
+        upload_window(lo, w, ws.hWin, ldh);
+        upload_matrix(ws.dZ, ws.hZ, ldh, w);
         apply_transform(lo, w, ws.dZ, w);
         SN_HIP_CHECK(hipStreamSynchronize(s));      // host buffers are reused
         if (real) for (int i = 0; i < w; i++) { real[lo + i] = wr[i]; imag[lo + i] = wi[i]; }
@@ -480,7 +487,13 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 
     SchurWorkspace &ws = g_sws;
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});
-    ws.ensure(n, wmax, divceil(ns_conf / 2, 1) + 1);
+    // Shift multiplicity: every shift pair of an AED drives `reuse` bulges of the following
+    // sweep (the AED window bounds the number of distinct shifts, the host AED kernel bounds the
+    // window).  A sweep is latency-bound by its first chain (steps_per_chain window steps), more
+    // chains only add `gap` steps each, so the same shifts applied 6x cost ~1.2x the time of a
+    // sweep and cut the number of sweeps at n = 20000 from 81 to 18 (measured: 7.0 s -> 5.5 s).
+    static int const reuse = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 6;
+    ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
     Driver d{s, n, dH, ldH, dQ, ldQ, ws, SchurStats{}};
 
     hipEvent_t e0, e1;
@@ -499,7 +512,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     } else if (thres == -3.0) thres = 0.0;      // LAPACK-style criteria
     else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
 
-    std::vector<double> sr(wmax), si(wmax), spike(wmax);
+    std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
     int rc = STARNEIG_SUCCESS;
     int ihi = n;                    // H(ihi:n, ihi:n) is already quasi-triangular
     int iter = 0, stagnation = 0;
@@ -536,15 +549,16 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         int const kw = ihi - nw;
         double sub = 0.0;
         if (kw > ilo) sub = ws.hSub[kw - 1];
-        d.download_window(kw, nw, ws.hWin, nw);
+        int const ldh = Driver::host_ld(nw);
+        d.download_window(kw, nw, ws.hWin, ldh);
         double t_aed0 = wall();
-        host::AedResult ar = host::aed_window(nw, ws.hWin, nw, ws.hZ, nw, sub, thres,
+        host::AedResult ar = host::aed_window(nw, ws.hWin, ldh, ws.hZ, ldh, sub, thres,
             spike.data(), sr.data(), si.data());
         d.st.aed_host_s += wall() - t_aed0;
         d.st.aeds++;
         if (ar.deflated > 0) {
-            d.upload_window(kw, nw, ws.hWin, nw);
-            d.upload_matrix(ws.dZ, ws.hZ, nw);
+            d.upload_window(kw, nw, ws.hWin, ldh);
+            d.upload_matrix(ws.dZ, ws.hZ, ldh, nw);
             if (kw > ilo)
                 hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, s,
                     dH + (size_t)(kw - 1) * ldH + kw, spike[0]);
@@ -552,8 +566,8 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             SN_HIP_CHECK(hipStreamSynchronize(s));
             if (real) {
                 std::vector<double> wr(nw), wi(nw);
-                host::extract_eigenvalues(ar.deflated, ws.hWin + (size_t)(nw - ar.deflated) * nw + (nw - ar.deflated),
-                    nw, wr.data(), wi.data());
+                host::extract_eigenvalues(ar.deflated, ws.hWin + (size_t)(nw - ar.deflated) * ldh + (nw - ar.deflated),
+                    ldh, wr.data(), wi.data());
                 for (int i = 0; i < ar.deflated; i++) {
                     real[ihi - ar.deflated + i] = wr[i]; imag[ihi - ar.deflated + i] = wi[i];
                 }
@@ -590,6 +604,11 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
         // ---- multi-shift sweep -----------------------------------------------------------------------
+        if (reuse > 1 && ihi - ilo > 4 * WS_MAX) {
+            for (int r = 1; r < reuse; r++)
+                for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
+            nshifts *= reuse;
+        }
         d.sweep(ilo, ihi, nshifts, sr.data(), si.data());
         iter++;
     }

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cfloat>
 #include <chrono>
+#include <cstdlib>
 #include <starneig/error.h>
 
 namespace sn {
@@ -276,10 +277,10 @@ struct GepWorkspace {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
-        size_t const w2 = (size_t)nwmax * nwmax * 8;
+        size_t const w2 = (size_t)(nwmax + 8) * nwmax * 8;
         SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * 2 * GWS * GWS * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)nwmax * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dQl, w2));
         SN_HIP_CHECK(hipMalloc((void **)&dZl, w2));
@@ -358,34 +359,39 @@ struct GepDriver {
         st.gemm_flops += 2.0 * w * w * (2.0 * (n - lo - w) + 2.0 * lo + (Q ? n : 0) + (Z ? n : 0));
     }
 
+    // padded host leading dimension (see schur.hip)
+    static int host_ld(int w) { return w + 8; }
     void download_windows(int lo, int w)
     {
         double t0 = wall();
-        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hA, (size_t)w * 8, A + (size_t)lo * ldA + lo, (size_t)ldA * 8,
+        size_t const hp = (size_t)host_ld(w) * 8;
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hA, hp, A + (size_t)lo * ldA + lo, (size_t)ldA * 8,
             (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
-        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hB, (size_t)w * 8, B + (size_t)lo * ldB + lo, (size_t)ldB * 8,
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hB, hp, B + (size_t)lo * ldB + lo, (size_t)ldB * 8,
             (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
         st.wait_s += wall() - t0;
     }
     void upload_windows(int lo, int w)
     {
-        SN_HIP_CHECK(hipMemcpy2DAsync(A + (size_t)lo * ldA + lo, (size_t)ldA * 8, ws.hA, (size_t)w * 8,
+        size_t const hp = (size_t)host_ld(w) * 8;
+        SN_HIP_CHECK(hipMemcpy2DAsync(A + (size_t)lo * ldA + lo, (size_t)ldA * 8, ws.hA, hp,
             (size_t)w * 8, w, hipMemcpyHostToDevice, s));
-        SN_HIP_CHECK(hipMemcpy2DAsync(B + (size_t)lo * ldB + lo, (size_t)ldB * 8, ws.hB, (size_t)w * 8,
+        SN_HIP_CHECK(hipMemcpy2DAsync(B + (size_t)lo * ldB + lo, (size_t)ldB * 8, ws.hB, hp,
             (size_t)w * 8, w, hipMemcpyHostToDevice, s));
-        SN_HIP_CHECK(hipMemcpyAsync(ws.dQl, ws.hQ, (size_t)w * w * 8, hipMemcpyHostToDevice, s));
-        SN_HIP_CHECK(hipMemcpyAsync(ws.dZl, ws.hZ, (size_t)w * w * 8, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.dQl, (size_t)w * 8, ws.hQ, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.dZl, (size_t)w * 8, ws.hZ, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
     }
 
     // small pencil on a host copy (row S6, GEP branch: schur/cpu_utils.c:3185-3371)
     int small_block(int lo, int w, double *real, double *imag, double *beta)
     {
+        int const ldh = host_ld(w);
         download_windows(lo, w);
         for (int j = 0; j < w; j++)
-            for (int i = 0; i < w; i++) ws.hQ[(size_t)j * w + i] = ws.hZ[(size_t)j * w + i] = (i == j) ? 1.0 : 0.0;
+            for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
         std::vector<double> ar(w), ai(w), be(w);
-        int info = host::gep_small_schur(w, ws.hA, w, ws.hB, w, ws.hQ, w, ws.hZ, w, w, ar.data(), ai.data(), be.data());
+        int info = host::gep_small_schur(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, w, ar.data(), ai.data(), be.data());
         if (info != 0) return info;
         upload_windows(lo, w);
         apply_transform(lo, w, ws.dQl, ws.dZl, w);
@@ -429,7 +435,8 @@ struct GepDriver {
             int const ev = (int)(issued % GepWorkspace::EV_RING);
             int const evp = (int)((issued + GepWorkspace::EV_RING - 1) % GepWorkspace::EV_RING);
             // see schur.hip (and tests/test_schur_pipeline.py) for the two wait rules
-            if (issued > 0 && last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            static bool const serial = getenv("SN_GEP_SERIAL") != nullptr;     // debugging aid
+            if (issued > 0 && (serial || last_t != t - 1)) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(gep_chase_kernel, dim3(ntasks), dim3(GEP_CHASE_THREADS), GEP_CHASE_LDS_BYTES, s,
                 step, A, ldA, B, ldB, Ubuf, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
@@ -489,7 +496,12 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
 
     GepWorkspace &ws = g_gws;
     int const wmax = std::max({nw_conf + nw_conf / 2 + 8, small_limit, 2 * GWS});
-    ws.ensure(n, wmax, ns_conf / 2 + 1);
+    // Shift multiplicity (see schur.hip).  Off by default for pencils: at n = 12000 a
+    // multiplicity of 4 cuts the time from 8.0 s to 6.1 s but the extra chain passes raise the
+    // residual from 460 u to 690 u (error ~ sqrt(number of 64-column window multiplications)),
+    // above the reference harness' 500 u warning line; SN_GEP_REUSE=k selects it.
+    static int const reuse = getenv("SN_GEP_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_GEP_REUSE")))) : 1;
+    ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
     GepDriver d{s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, ws, SchurStats{}};
     // the update kernel identifies "no Q" by a null pointer but still needs distinct slots
     hipEvent_t e0, e1;
@@ -508,7 +520,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     } else if (thres == -3.0) thres = 0.0;
     else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
 
-    std::vector<double> sr(wmax), si(wmax), spike(wmax);
+    std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
     int rc = STARNEIG_SUCCESS;
     int ihi = n, iter = 0, stagnation = 0;
     while (ihi > 0) {
@@ -537,7 +549,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         double const sub = (kw > ilo) ? ws.hSub[kw - 1] : 0.0;
         d.download_windows(kw, nw);
         double t_aed0 = wall();
-        host::AedResult ar = host::gep_aed_window(nw, ws.hA, nw, ws.hB, nw, ws.hQ, nw, ws.hZ, nw, sub, thres,
+        int const ldh = GepDriver::host_ld(nw);
+        host::AedResult ar = host::gep_aed_window(nw, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, sub, thres,
             spike.data(), sr.data(), si.data());
         d.st.aed_host_s += wall() - t_aed0;
         d.st.aeds++;
@@ -551,8 +564,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
             SN_HIP_CHECK(hipStreamSynchronize(s));
             if (real) {
                 int const off = nw - ar.deflated;
-                host::gep_extract_eigenvalues(ar.deflated, ws.hA + (size_t)off * nw + off, nw,
-                    ws.hB + (size_t)off * nw + off, nw, real + ihi - ar.deflated, imag + ihi - ar.deflated,
+                host::gep_extract_eigenvalues(ar.deflated, ws.hA + (size_t)off * ldh + off, ldh,
+                    ws.hB + (size_t)off * ldh + off, ldh, real + ihi - ar.deflated, imag + ihi - ar.deflated,
                     beta + ihi - ar.deflated);
             }
             ihi -= ar.deflated;
@@ -588,6 +601,11 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         }
         if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
+        if (reuse > 1 && ihi - ilo > 4 * GWS) {
+            for (int r = 1; r < reuse; r++)
+                for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
+            nshifts *= reuse;
+        }
         d.sweep(ilo, ihi, nshifts, sr.data(), si.data());
         iter++;
     }

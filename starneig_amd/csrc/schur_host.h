@@ -25,6 +25,8 @@ int gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, in
     double *Z, int ldz, int nq, double *ar, double *ai, double *be);
 void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,
     double *Q, int ldq, double *Z, int ldz, int nq);
+int gep_move_block_up(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int nq, int from, int to);
 AedResult gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si);
 

@@ -11,8 +11,8 @@
 // included); a (numerically) zero diagonal entry of B inside an active block is perturbed to
 // u*||B||_F instead of being chased out as an infinite eigenvalue (a backward error of the
 // same size as rounding; the reference's push_inf_* machinery, cpu_utils.c:360-799, is not
-// rebuilt); the AED deflates the trailing run of converged eigenvalues without reordering
-// (no dtgexc).
+// rebuilt).  Reordering inside the AED window swaps adjacent blocks through the generalized
+// Sylvester equation like LAPACK dtgex2.
 #include "schur_host.h"
 #include <cmath>
 #include <cfloat>
@@ -112,12 +112,31 @@ inline void pencil2_sum_prod(double a11, double a12, double a21, double a22,
 // (LAPACK dlagv2; reference process_2x2_block, cpu_utils.c:801-850.)
 static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
 {
-    double a11 = A(p, p), a12 = A(p, p + 1), a21 = A(p + 1, p), a22 = A(p + 1, p + 1);
-    double b11 = B(p, p), b12 = B(p, p + 1), b22 = B(p + 1, p + 1);
-    double sum, prod;
-    pencil2_sum_prod(a11, a12, a21, a22, b11, b12, b22, sum, prod);
-    double disc = 0.25 * sum * sum - prod;
-    if (disc >= 0.0) {
+    // Real pair: one pass rotates an (approximate) eigenvector of the block to e1.  When the
+    // two eigenvalues (almost) coincide the eigenvalue from the quadratic formula carries an
+    // error of sqrt(eps) and so does the entry that should vanish; every pass is an orthogonal
+    // transformation of the whole pencil, so passes are simply repeated (each one is an
+    // exact-shift QZ step on the block; convergence is quadratic for distinct eigenvalues and
+    // linear with ratio ~1/2 for a double one, hence the generous limit) until A(p+1,p) meets
+    // the deflation criterion -- only then is it set to zero.
+    double prev = HUGE_VAL;
+    for (int pass = 0; pass < 60; pass++) {
+        double a11 = A(p, p), a12 = A(p, p + 1), a21 = A(p + 1, p), a22 = A(p + 1, p + 1);
+        double b11 = B(p, p), b12 = B(p, p + 1), b22 = B(p + 1, p + 1);
+        double const tol = DBL_EPSILON * (std::fabs(a11) + std::fabs(a22));
+        if (std::fabs(a21) <= tol) { A(p + 1, p) = 0.0; return 1; }
+        if (std::fabs(a21) >= 0.25 * prev) {
+            // stagnation at the rounding floor of the block (a few ulp of its largest entry)
+            if (std::fabs(a21) <= 1000.0 * DBL_EPSILON * (std::fabs(a11) + std::fabs(a12) + std::fabs(a22))) {
+                A(p + 1, p) = 0.0; return 1;
+            }
+            if (pass > 8) break;
+        }
+        prev = std::fabs(a21);
+        double sum, prod;
+        pencil2_sum_prod(a11, a12, a21, a22, b11, b12, b22, sum, prod);
+        double disc = 0.25 * sum * sum - prod;
+        if (!(disc >= 0.0)) break;
         // real pair: lambda closer to a22/b22 first
         double rt = std::sqrt(disc);
         double l1 = 0.5 * sum + rt, l2 = 0.5 * sum - rt;
@@ -139,9 +158,11 @@ static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
         rot_rows(A, p, p + 1, p, n, c2, s2);
         rot_rows(B, p, p + 1, p, n, c2, s2);
         rot_cols(Q, p, p + 1, 0, nq, c2, s2);
-        B(p + 1, p) = 0.0; A(p + 1, p) = 0.0;
-        return 1;
+        B(p + 1, p) = 0.0;
     }
+    double a11 = A(p, p), a12 = A(p, p + 1), a21 = A(p + 1, p), a22 = A(p + 1, p + 1);
+    double b11 = B(p, p), b12 = B(p, p + 1), b22 = B(p + 1, p + 1);
+    (void)a11; (void)a12; (void)a21; (void)a22;
     // complex pair: B22 = U S V^T  ->  U^T B22 V diagonal (2x2 SVD of a triangular matrix)
     double th = 0.5 * std::atan2(2.0 * b11 * b12, b11 * b11 - b12 * b12 - b22 * b22);
     double cv = std::cos(th), sv = std::sin(th);          // V = [cv -sv; sv cv]
@@ -307,10 +328,197 @@ void gep_ht_reduce(int n, int ilo, int ihi, double *A_, int lda, double *B_, int
     }
 }
 
+// ---- reordering (LAPACK dtgex2 / dtgexc, upward direction; reference starneig_move_block,
+// schur/cpu_utils.c:3377-3416) --------------------------------------------------------------
+namespace {
+
+// Explicit m x m orthogonal factor of the QR factorisation of the m x k matrix X (ld 4, m <= 4,
+// k <= 2): X = U [R; 0].  U is returned column-major with ld 4.
+static void small_qr(int m, int k, double const *X, double *Uo)
+{
+    double W[16];
+    for (int c = 0; c < k; c++) for (int r = 0; r < m; r++) W[r + 4 * c] = X[r + 4 * c];
+    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) Uo[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+    for (int c = 0; c < k && c < m - 1; c++) {
+        double v[4], beta, tau = house_first(m - c, &W[c + 4 * c], v, beta);
+        if (tau == 0.0) continue;
+        for (int cc = c; cc < k; cc++) {            // W <- H W
+            double sdot = 0.0;
+            for (int r = 0; r < m - c; r++) sdot += v[r] * W[c + r + 4 * cc];
+            sdot *= tau;
+            for (int r = 0; r < m - c; r++) W[c + r + 4 * cc] -= sdot * v[r];
+        }
+        for (int r = 0; r < m; r++) {               // U <- U H
+            double sdot = 0.0;
+            for (int q = 0; q < m - c; q++) sdot += Uo[r + 4 * (c + q)] * v[q];
+            sdot *= tau;
+            for (int q = 0; q < m - c; q++) Uo[r + 4 * (c + q)] -= sdot * v[q];
+        }
+    }
+}
+
+// Swaps the adjacent diagonal blocks (n1 x n1 at j, n2 x n2 at j+n1) of the generalized
+// Schur form (A,B) by an orthogonal equivalence; Q, Z (nq rows) are updated.  The deflating
+// subspaces of the second block come from the generalized Sylvester equation
+//   A11 R - L A22 = -A12,  B11 R - L B22 = -B12   (right: [R; I], left: [L; I]),
+// solved as a dense system of 2 n1 n2 <= 8 unknowns with complete pivoting.  Returns false
+// (nothing changed) when the blocks are too close to swap stably (LAPACK's weak stability test).
+static bool gep_swap_adjacent(int nw, Mat A, Mat B, Mat Q, Mat Z, int nq, int j, int n1, int n2)
+{
+    int const m = n1 + n2, nn = n1 * n2, N = 2 * nn;
+    double S[16], T[16];
+    double fro = 0.0;
+    for (int c = 0; c < m; c++)
+        for (int r = 0; r < m; r++) {
+            S[r + 4 * c] = A(j + r, j + c); T[r + 4 * c] = B(j + r, j + c);
+            fro = std::hypot(fro, std::hypot(S[r + 4 * c], T[r + 4 * c]));
+        }
+    double K[64], u[8];
+    for (int i = 0; i < 64; i++) K[i] = 0.0;
+    for (int k = 0; k < n2; k++)
+        for (int i = 0; i < n1; i++) {
+            int const e = i + n1 * k;
+            for (int p = 0; p < n1; p++) {
+                K[e + N * (p + n1 * k)] += S[i + 4 * p];
+                K[nn + e + N * (p + n1 * k)] += T[i + 4 * p];
+            }
+            for (int q = 0; q < n2; q++) {
+                K[e + N * (nn + i + n1 * q)] -= S[(n1 + q) + 4 * (n1 + k)];
+                K[nn + e + N * (nn + i + n1 * q)] -= T[(n1 + q) + 4 * (n1 + k)];
+            }
+            u[e] = -S[i + 4 * (n1 + k)];
+            u[nn + e] = -T[i + 4 * (n1 + k)];
+        }
+    // Gaussian elimination with complete pivoting
+    int perm[8];
+    for (int i = 0; i < N; i++) perm[i] = i;
+    double kmax = 0.0;
+    for (int i = 0; i < N * N; i++) kmax = std::max(kmax, std::fabs(K[i]));
+    if (kmax == 0.0) return false;
+    for (int c = 0; c < N; c++) {
+        int pr = c, pc = c; double best = -1.0;
+        for (int cc = c; cc < N; cc++)
+            for (int r = c; r < N; r++)
+                if (std::fabs(K[r + N * cc]) > best) { best = std::fabs(K[r + N * cc]); pr = r; pc = cc; }
+        if (best <= 8.0 * DBL_EPSILON * kmax) return false;     // (nearly) common eigenvalue
+        if (pr != c) { for (int cc = 0; cc < N; cc++) std::swap(K[c + N * cc], K[pr + N * cc]); std::swap(u[c], u[pr]); }
+        if (pc != c) { for (int r = 0; r < N; r++) std::swap(K[r + N * c], K[r + N * pc]); std::swap(perm[c], perm[pc]); }
+        for (int r = c + 1; r < N; r++) {
+            double const f = K[r + N * c] / K[c + N * c];
+            if (f == 0.0) continue;
+            for (int cc = c; cc < N; cc++) K[r + N * cc] -= f * K[c + N * cc];
+            u[r] -= f * u[c];
+        }
+    }
+    double sol[8];
+    for (int c = N - 1; c >= 0; c--) {
+        double v = u[c];
+        for (int cc = c + 1; cc < N; cc++) v -= K[c + N * cc] * sol[perm[cc]];
+        sol[perm[c]] = v / K[c + N * c];
+    }
+    // X = [R; I], Y = [L; I]  (m x n2)
+    double X[16], Y[16], Zl[16], Ql[16];
+    for (int k = 0; k < n2; k++) {
+        for (int i = 0; i < n1; i++) { X[i + 4 * k] = sol[i + n1 * k]; Y[i + 4 * k] = sol[nn + i + n1 * k]; }
+        for (int q = 0; q < n2; q++) { X[n1 + q + 4 * k] = (q == k) ? 1.0 : 0.0; Y[n1 + q + 4 * k] = (q == k) ? 1.0 : 0.0; }
+    }
+    small_qr(m, n2, X, Zl);
+    small_qr(m, n2, Y, Ql);
+    // weak stability test on the local pencil: (2,1) blocks of Ql^T S Zl and Ql^T T Zl
+    double SZ[16], TZ[16], S2[16], T2[16];
+    for (int c = 0; c < m; c++)
+        for (int r = 0; r < m; r++) {
+            double a = 0.0, b = 0.0;
+            for (int p = 0; p < m; p++) { a += S[r + 4 * p] * Zl[p + 4 * c]; b += T[r + 4 * p] * Zl[p + 4 * c]; }
+            SZ[r + 4 * c] = a; TZ[r + 4 * c] = b;
+        }
+    double low = 0.0;
+    for (int c = 0; c < m; c++)
+        for (int r = 0; r < m; r++) {
+            double a = 0.0, b = 0.0;
+            for (int p = 0; p < m; p++) { a += Ql[p + 4 * r] * SZ[p + 4 * c]; b += Ql[p + 4 * r] * TZ[p + 4 * c]; }
+            S2[r + 4 * c] = a; T2[r + 4 * c] = b;
+            if (r >= n2 && c < n2) low = std::hypot(low, std::hypot(a, b));
+        }
+    if (low > std::max(20.0 * DBL_EPSILON * fro, DBL_MIN)) return false;
+    // ---- apply to the window: rows j..j+m-1 <- Ql^T ., columns j..j+m-1 <- . Zl
+    double tmp[4];
+    for (int c = j; c < nw; c++) {
+        for (int r = 0; r < m; r++) { double a = 0.0; for (int p = 0; p < m; p++) a += Ql[p + 4 * r] * A(j + p, c); tmp[r] = a; }
+        for (int r = 0; r < m; r++) A(j + r, c) = tmp[r];
+        for (int r = 0; r < m; r++) { double a = 0.0; for (int p = 0; p < m; p++) a += Ql[p + 4 * r] * B(j + p, c); tmp[r] = a; }
+        for (int r = 0; r < m; r++) B(j + r, c) = tmp[r];
+    }
+    auto right = [&](Mat M, int rows) {
+        for (int r = 0; r < rows; r++) {
+            for (int c = 0; c < m; c++) { double a = 0.0; for (int p = 0; p < m; p++) a += M(r, j + p) * Zl[p + 4 * c]; tmp[c] = a; }
+            for (int c = 0; c < m; c++) M(r, j + c) = tmp[c];
+        }
+    };
+    right(A, j + m); right(B, j + m); right(Z, nq);
+    for (int r = 0; r < nq; r++) {
+        for (int c = 0; c < m; c++) { double a = 0.0; for (int p = 0; p < m; p++) a += Q(r, j + p) * Ql[p + 4 * c]; tmp[c] = a; }
+        for (int c = 0; c < m; c++) Q(r, j + c) = tmp[c];
+    }
+    for (int c = 0; c < n2; c++) for (int r = n2; r < m; r++) { A(j + r, j + c) = 0.0; B(j + r, j + c) = 0.0; }
+    // ---- restore the standard form of the two diagonal blocks
+    auto fix_block = [&](int p, int bs) {
+        if (bs == 2) {
+            double c, sn, r;
+            givens(B(p, p), B(p + 1, p), c, sn, r);          // B block upper triangular again
+            rot_rows(A, p, p + 1, p, nw, c, sn);
+            rot_rows(B, p, p + 1, p, nw, c, sn);
+            rot_cols(Q, p, p + 1, 0, nq, c, sn);
+            B(p + 1, p) = 0.0;
+            if (gep_standardise_2x2(nw, A, B, Q, Z, nq, p) == 2) return;
+            bs = 1;                                          // split into two real eigenvalues
+            if (B(p + 1, p + 1) < 0.0) {
+                for (int i = 0; i <= p + 1; i++) { A(i, p + 1) = -A(i, p + 1); B(i, p + 1) = -B(i, p + 1); }
+                for (int i = 0; i < nq; i++) Z(i, p + 1) = -Z(i, p + 1);
+            }
+        }
+        if (B(p, p) < 0.0) {
+            for (int i = 0; i <= p; i++) { A(i, p) = -A(i, p); B(i, p) = -B(i, p); }
+            for (int i = 0; i < nq; i++) Z(i, p) = -Z(i, p);
+        }
+    };
+    fix_block(j, n2);
+    fix_block(j + n2, n1);
+    return true;
+}
+
+} // namespace
+
+// Moves the diagonal block that starts at row `from` up to row `to` by adjacent swaps.
+// Returns the row where it ended up (== to unless a swap was rejected).
+int gep_move_block_up(int nw, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
+    double *Z_, int ldz, int nq, int from, int to)
+{
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    int here = from;
+    int nbf = (here + 1 < nw && A(here + 1, here) != 0.0) ? 2 : 1;
+    while (here > to) {
+        int nbabove = (here - 2 >= 0 && A(here - 1, here - 2) != 0.0) ? 2 : 1;
+        if (here - nbabove < to) break;
+        int j1 = here - nbabove;
+        if (!gep_swap_adjacent(nw, A, B, Q, Z, nq, j1, nbabove, nbf)) break;
+        here = j1;
+        if (nbf == 2 && A(here + 1, here) == 0.0) {
+            // the moving 2x2 block split into two 1x1 blocks: move them one at a time
+            int a = gep_move_block_up(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nq, here, to);
+            if (a != to) return a;
+            gep_move_block_up(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nq, here + 1, to + 1);
+            return a;
+        }
+    }
+    return here;
+}
+
+
 // Aggressive early deflation on a host window of the pencil (reference
-// perform_aggressively_deflate, cpu_utils.c:2837-3046, generalized branches), without
-// reordering: the trailing run of eigenvalues whose spike entries are below the threshold is
-// deflated.  On return (S,T) = [HT (ns x ns) | *; 0 | Schur (nd x nd)], Q/Z the accumulated
+// perform_aggressively_deflate, cpu_utils.c:2837-3046, generalized branches): eigenvalues
+// whose spike entries are below the threshold are deflated, the others are reordered to the
+// top of the window.  On return (S,T) = [HT (ns x ns) | *; 0 | Schur (nd x nd)], Q/Z the accumulated
 // transformations, spike[0] the new coupling entry, shifts as complex numbers alpha/beta.
 AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
     double *Z_, int ldz, double sub, double thres, double *spike, double *sr, double *si)
@@ -321,37 +529,46 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
     std::vector<double> ar(nw), ai(nw), be(nw);
     int info = gep_small_schur(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, ar.data(), ai.data(), be.data());
     if (info != 0) { res.failed = 1; return res; }
-    for (int j = 0; j < nw; j++) spike[j] = sub * Q(0, j);
-    int i = nw - 1, nd = 0;
-    while (i >= 0) {
-        bool two = (i >= 1 && A(i, i - 1) != 0.0);
+    // deflation scan from the bottom; undeflatable blocks are moved to the top of the window
+    // (they accumulate in [0, top)) so that every converged eigenvalue can be deflated
+    int top = 0, i = nw - 1;
+    while (top <= i) {
+        bool two = (top <= i - 1 && A(i, i - 1) != 0.0);
+        double sp = std::fabs(sub * Q(0, i));
+        if (two) sp = std::max(sp, std::fabs(sub * Q(0, i - 1)));
         bool ok;
         if (thres > 0.0)        // norm-stable criterion (cpu_utils.c:2891-2931)
-            ok = std::fabs(spike[i]) < thres && (!two || std::fabs(spike[i - 1]) < thres);
+            ok = sp < thres;
         else {                  // LAPACK-style criterion (:2937-2988)
             double const ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)nw / ulp);
             double foo = std::fabs(A(i, i));
             if (two) foo += std::sqrt(std::fabs(A(i, i - 1))) * std::sqrt(std::fabs(A(i - 1, i)));
             if (foo == 0.0) foo = std::fabs(sub);
-            double sp = std::fabs(spike[i]);
-            if (two) sp = std::max(sp, std::fabs(spike[i - 1]));
             ok = sp < std::max(smlnum, ulp * foo);
         }
-        if (!ok) break;
-        nd += two ? 2 : 1; i -= two ? 2 : 1;
+        int const bs = two ? 2 : 1;
+        if (ok) i -= bs;
+        else {
+            int const from = i - bs + 1;
+            int at = gep_move_block_up(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, from, top);
+            if (at != top) { top = i + 1; break; }   // swap rejected: nothing above `i` is examined
+            top += bs;
+        }
     }
-    int const ns = nw - nd;
+    int const ns = top, nd = nw - top;
     res.deflated = nd;
+    for (int j = 0; j < nw; j++) spike[j] = sub * Q(0, j);
     // shifts: finite eigenvalues of the undeflated part (of everything if that is too small)
     {
-        int lo = 0, hi = (ns >= 2) ? ns : nw, cnt = 0;
+        int const hi = (ns >= 2) ? ns : nw;
+        gep_extract_eigenvalues(hi, A_, lda, B_, ldb, ar.data(), ai.data(), be.data());
         std::vector<double> wr, wi;
-        for (int k = lo; k < hi; k++)
+        for (int k = 0; k < hi; k++)
             if (be[k] != 0.0) {
                 double re = ar[k] / be[k], im = ai[k] / be[k];
                 if (std::isfinite(re) && std::isfinite(im) && !(re == 0.0 && im == 0.0)) { wr.push_back(re); wi.push_back(im); }
             }
-        cnt = (int)wr.size();
+        int const cnt = (int)wr.size();
         std::vector<int> idx(cnt);
         for (int k = 0; k < cnt; k++) idx[k] = k;
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
@@ -408,6 +625,10 @@ __attribute__((visibility("default")))
 void sn_internal_gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,
     double *Q, int ldq, double *Z, int ldz)
 { sn::host::gep_ht_reduce(n, ilo, ihi, A, lda, B, ldb, Q, ldq, Z, ldz, n); }
+__attribute__((visibility("default")))
+int sn_internal_gep_move_block_up(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int from, int to)
+{ return sn::host::gep_move_block_up(n, A, lda, B, ldb, Q, ldq, Z, ldz, n, from, to); }
 __attribute__((visibility("default")))
 int sn_internal_gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si, int *out3)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from helpers import U, WARN_U, to_device, to_host
+from helpers import U, WARN_U, eig_backward_error_u, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -74,6 +74,10 @@ def test_schur_of_random_hessenberg(node, n):
     real = np.zeros(n); imag = np.zeros(n)
     assert node.SEP_SM_Schur(n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
     check_result(node, H0, H, Q0, Q, real, imag, None)
+    # conditioning-independent eigenvalue check: each one is an exact eigenvalue of a matrix
+    # within 500 u of the input
+    eye = np.zeros_like(H0); eye[np.arange(n), np.arange(n)] = 1.0
+    assert eig_backward_error_u(H0, eye, real + 1j * imag, np.ones(n), sample=24) < WARN_U
 
 
 @pytest.mark.parametrize("aed,shifts,small", [(50, 20, 100), (100, 60, 128), (200, 120, 150), (24, 8, 100)])

@@ -111,3 +111,78 @@ def test_gep_aed_window_invariants(nw, sub):
     assert np.all(spike[1:] == 0.0)
     assert abs(abs(spike[0]) - np.linalg.norm(full[:ns])) <= 1e3 * U * abs(sub)
     assert np.all(np.abs(full[ns:]) < thres * 1.001)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gep_move_block_up_reorders_eigenvalues(seed):
+    """every block of a generalized Schur form can be bubbled to the top; the eigenvalue moves
+    with it and the decomposition stays intact (LAPACK dtgexc semantics)"""
+    n = 24
+    A0, B0 = random_ht_pencil(n, seed=seed)
+    L = lib()
+    L.sn_internal_gep_move_block_up.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [C.c_int, C.c_int]
+    L.sn_internal_gep_move_block_up.restype = C.c_int
+    Sm, Tm = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.asfortranarray(np.eye(n)); Z = np.asfortranarray(np.eye(n))
+    ar = np.zeros(n); ai = np.zeros(n); be = np.zeros(n)
+    assert L.sn_internal_gep_small_schur(n, P(Sm), n, P(Tm), n, P(Q), n, P(Z), n, P(ar), P(ai), P(be)) == 0
+    ev0 = np.sort_complex((ar + 1j * ai) / be)
+    moved = 0
+    for trial in range(12):
+        sub = np.diag(Sm, -1)
+        starts = [i for i in range(n) if i == 0 or sub[i - 1] == 0.0]
+        src = starts[(5 * trial + 3) % len(starts)]
+        if src == 0:
+            continue
+        two = src + 1 < n and Sm[src + 1, src] != 0.0
+        lam = (Sm[src, src] / Tm[src, src]) if not two else None
+        at = L.sn_internal_gep_move_block_up(n, P(Sm), n, P(Tm), n, P(Q), n, P(Z), n, src, 0)
+        check_gschur(A0, B0, Sm, Tm, Q, Z)
+        if at == 0:
+            moved += 1
+            if lam is not None:
+                assert abs(Sm[0, 0] / Tm[0, 0] - lam) <= 1e-9 * max(1.0, abs(lam))
+        er = np.zeros(n); ei = np.zeros(n); eb = np.zeros(n)
+        O.lib().oracle_gep_extract_eigenvalues(n, P(Sm), n, P(Tm), n, P(er), P(ei), P(eb))
+        assert O.match_eigenvalues((er + 1j * ei) / eb, ev0) < 1e7
+    assert moved >= 6
+
+
+def test_gep_aed_window_reorders_to_deflate_more():
+    """with reordering the AED deflates converged eigenvalues from anywhere in the window: a
+    pencil that is already triangular with a spike that is tiny except for a few entries must
+    deflate all the others"""
+    nw = 30
+    rng = np.random.RandomState(5)
+    A0 = np.asfortranarray(np.triu(rng.uniform(-1, 1, (nw, nw))) + np.diag(np.arange(1.0, nw + 1.0)))
+    B0 = np.asfortranarray(np.triu(rng.uniform(-1, 1, (nw, nw)) * 0.1) + np.eye(nw))
+    A, B = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.zeros((nw, nw), order="F"); Z = np.zeros((nw, nw), order="F")
+    spike = np.zeros(nw); sr = np.zeros(nw); si = np.zeros(nw); out = (C.c_int * 3)()
+    # triangular input: Q = I after the (trivial) Schur step, so spike = sub * e_1: only the first
+    # eigenvalue is coupled and all others deflate -- but it sits at the TOP, the scan from the
+    # bottom passes 29 deflatable eigenvalues first
+    lib().sn_internal_gep_aed_window(nw, P(A), nw, P(B), nw, P(Q), nw, P(Z), nw, 1e-3, 1e-10,
+                                     P(spike), P(sr), P(si), out)
+    assert out[2] == 0 and out[0] == nw - 1
+    # and with a spike hitting a middle eigenvalue (rotate the pencil so that Q(0,:) has two entries)
+    A, B = A0.copy(order="F"), B0.copy(order="F")
+    G = np.eye(nw); c, s = np.cos(0.3), np.sin(0.3); k = 17
+    # swap roles by an explicit equivalence that keeps triangularity: not possible with a plain
+    # rotation, so instead check the general invariants on a random window with a loose threshold
+    A0r, B0r = random_ht_pencil(60, seed=11)
+    A, B = A0r.copy(order="F"), B0r.copy(order="F")
+    Q = np.zeros((60, 60), order="F"); Z = np.zeros((60, 60), order="F")
+    spike = np.zeros(60); sr = np.zeros(60); si = np.zeros(60)
+    thres = 0.02 * 1e-3          # deflate whatever has |Q(0,i)| < 0.02
+    lib().sn_internal_gep_aed_window(60, P(A), 60, P(B), 60, P(Q), 60, P(Z), 60, 1e-3, thres,
+                                     P(spike), P(sr), P(si), out)
+    nd = out[0]; ns = 60 - nd
+    assert out[2] == 0 and nd > 0
+    full = 1e-3 * Q[0, :]
+    assert np.all(np.abs(full[ns:]) < thres * 1.001)
+    assert np.linalg.norm(Q @ Q.T - np.eye(60)) <= 500 * U * np.sqrt(60)
+    # what is dropped is exactly the deflated spike entries
+    E = Q @ A @ Z.T - A0r
+    assert np.linalg.norm(E) <= 1000 * U * np.linalg.norm(A0r)
+    assert np.all(np.tril(A, -2) == 0.0) and np.all(np.tril(B, -1) == 0.0) and np.all(A[ns:, :ns] == 0.0)
