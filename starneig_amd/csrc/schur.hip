@@ -34,8 +34,8 @@ constexpr int WS_MAX = 96;          // diagonal window (rows) held in LDS
 constexpr int NB_MAX = 15;          // bulges per chain: 3*NB_MAX+1 <= WS_MAX/2 + ...
 constexpr int LDW = WS_MAX + 1;     // odd leading dimension: conflict-free row AND column walks
 constexpr int CHASE_THREADS = 1024; // 16 waves share one window
-constexpr int UPDATE_LDS_BYTES_L = GemmCfg<128, 128, 16, true, false>::LDS_BYTES;
-constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, 128, 16, false, false>::LDS_BYTES;
+constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BYTES;
+constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 8 * NB_MAX + 16) * 8;
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
@@ -150,7 +150,7 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
 //   MODE 1         : H(above win, win) <- . U and (blockIdx.y >= ntasks) Q(:, win) <- . U.
 // MODE 0/1 run on a second stream concurrently with the next chase launch (chains are
 // spaced ws+adv rows apart so that no other chain's next window touches them).
-// One workgroup owns all w <= 128 rows (columns) of its tile and reads its whole operand
+// One workgroup owns all w <= WS_MAX = 96 rows (columns) of its tile (96-wide MFMA tiles: no padding) and reads its whole operand
 // panel before the epilogue writes, so the update is done in place.
 template <int MODE>
 __global__ __launch_bounds__(256, 2)
@@ -168,14 +168,14 @@ void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
         if (MODE == 2) ncols = min(ncols, step.adv);
         if ((int)blockIdx.x * 128 >= ncols) return;
         double *X = H + (size_t)c0 * ldH + lo;
-        gemm_tile<128, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH,
+        gemm_tile<WS_MAX, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH,
             0, blockIdx.x);
     } else {
         int const rows = is_q ? n : lo;
         if ((int)blockIdx.x * 128 >= rows) return;
         double *X = is_q ? Q + (size_t)lo * ldQ : H + (size_t)lo * ldH;
         int const ld = is_q ? ldQ : ldH;
-        gemm_tile<128, 128, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, WS_MAX, 0.0, X, ld,
+        gemm_tile<128, WS_MAX, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, WS_MAX, 0.0, X, ld,
             blockIdx.x, 0);
     }
 }
@@ -471,11 +471,12 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     int const min_val = lapack_min_shifts(n);
     int nw_default = (int)std::max(min_val / 0.7, 0.08 * n);
     int ns_default = (int)std::max((double)min_val, 0.06 * n);
-    // the AED window is reduced on the host in this revision (O(w^3) scalar work per call):
-    // the measured optimum at n = 20000 is 192 / 128 (8.2 s vs 19.6 s at 384 / 256);
-    // explicit conf values are honoured up to 1024
-    nw_default = std::min(nw_default, 192);
-    ns_default = std::min(ns_default, 128);
+    // the AED window is reduced on the host in this revision (O(w^3) scalar work per call) and
+    // every shift pair drives several bulges (see `reuse` below): the measured optimum at
+    // n = 20000 is 160 / 106 (4.6 s; 5.0 s at 192 / 128, 6.0 s at 224 / 150, 13 s at 256 / 170
+    // where the host kernel falls out of cache); explicit conf values are honoured up to 1024
+    nw_default = std::min(nw_default, 160);
+    ns_default = std::min(ns_default, 106);
     int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 1024) : nw_default;
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : ns_default;
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
@@ -490,9 +491,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // Shift multiplicity: every shift pair of an AED drives `reuse` bulges of the following
     // sweep (the AED window bounds the number of distinct shifts, the host AED kernel bounds the
     // window).  A sweep is latency-bound by its first chain (steps_per_chain window steps), more
-    // chains only add `gap` steps each, so the same shifts applied 6x cost ~1.2x the time of a
-    // sweep and cut the number of sweeps at n = 20000 from 81 to 18 (measured: 7.0 s -> 5.5 s).
-    static int const reuse = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 6;
+    // chains only add `gap` steps each, so the same shifts applied 8x cost ~1.3x the time of a
+    // sweep and cut the number of sweeps at n = 20000 from 81 to 13 (measured: 7.0 s -> 5.4 s at
+    // a 192-row AED window).
+    static int const reuse = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 8;
     ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
     Driver d{s, n, dH, ldH, dQ, ldQ, ws, SchurStats{}};
 
@@ -604,6 +606,16 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
         // ---- multi-shift sweep -----------------------------------------------------------------------
+        {
+            static bool const stale = getenv("SN_SCHUR_STALE") != nullptr;     // experiment
+            static std::vector<double> psr, psi; static int pn = 0;
+            if (stale) {
+                std::vector<double> csr(sr.begin(), sr.begin() + nshifts), csi(si.begin(), si.begin() + nshifts);
+                int cn = nshifts;
+                if (pn >= 2) { nshifts = pn; for (int k = 0; k < pn; k++) { sr[k] = psr[k]; si[k] = psi[k]; } }
+                psr = csr; psi = csi; pn = cn;
+            }
+        }
         if (reuse > 1 && ihi - ilo > 4 * WS_MAX) {
             for (int r = 1; r < reuse; r++)
                 for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
