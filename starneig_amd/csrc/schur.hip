@@ -36,6 +36,7 @@ constexpr int LDW = WS_MAX + 1;     // odd leading dimension: conflict-free row 
 constexpr int CHASE_THREADS = 1024; // 16 waves share one window
 constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
+constexpr int UPDATE_LDS_BYTES_P = UPDATE_LDS_BYTES_L > UPDATE_LDS_BYTES_R ? UPDATE_LDS_BYTES_L : UPDATE_LDS_BYTES_R;
 constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 8 * NB_MAX + 16) * 8;
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
@@ -147,37 +148,74 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
 //   MODE 2 ("near"): H(win, next `adv` columns right of win) <- U^T .  -- the only part of the
 //                    updates the chain's NEXT window needs; stays on the critical stream.
 //   MODE 0 ("far") : the remaining columns right of the window.
-//   MODE 1         : H(above win, win) <- . U and (blockIdx.y >= ntasks) Q(:, win) <- . U.
+//   MODE 1         : H(above win, win) <- . U
+//   MODE 3         : Q(:, win) <- . U
 // MODE 0/1 run on a second stream concurrently with the next chase launch (chains are
 // spaced ws+adv rows apart so that no other chain's next window touches them).
+// Timely and lazy zones: the iteration only ever reads H inside the band of rows between the
+// rearmost chain and the bottom of the active block, and in columns left of ihi.  Updates of
+//   - Q,
+//   - H(:, ihi:n)          (the columns of the already deflated part, MODE 0), and
+//   - H(0:T0, :)           (rows above the rearmost chain and above the guard row R1, MODE 1)
+// are "lazy": they run in issue order on a third, low-priority stream and fill the time the GPU
+// would otherwise idle while the host reduces AED windows.  [r0, r1) selects the column
+// (MODE 0) or row (MODE 1) range of a launch.
 // One workgroup owns all w <= WS_MAX = 96 rows (columns) of its tile (96-wide MFMA tiles: no padding) and reads its whole operand
 // panel before the epilogue writes, so the update is done in place.
 template <int MODE>
-__global__ __launch_bounds__(256, 2)
-void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
-    double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U)
+__device__ __forceinline__
+void schur_update_body(SweepStep const &step, double *__restrict__ H, int ldH,
+    double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U, int r0, int r1, int bx, int by)
 {
-    int const k = blockIdx.y % step.ntasks;
-    bool const is_q = (int)blockIdx.y >= step.ntasks;
+    int const k = by % step.ntasks;
     ChaseTask const t = make_task(step, k);
     double const *Uk = U + (size_t)k * WS_MAX * WS_MAX;
     int const w = t.n, lo = t.lo;
     if (MODE == 0 || MODE == 2) {
-        int const c0 = (MODE == 2) ? lo + w : lo + w + step.adv;
-        int ncols = n - c0;
-        if (MODE == 2) ncols = min(ncols, step.adv);
-        if ((int)blockIdx.x * 128 >= ncols) return;
+        // MODE 2: columns [lo+w, lo+w+adv) left of ihi (the deflated columns are lazy);
+        // MODE 0: the columns right of the near strip (timely launch, r1 <= ihi) or right of the
+        //         window (lazy launch, r0 >= ihi) that fall into [r0, r1)
+        int c0 = lo + w, cend = n;
+        if (MODE == 2) cend = min(step.ihi, c0 + step.adv);
+        else {
+            if (r0 < step.ihi) c0 += step.adv;
+            c0 = max(c0, r0); cend = min(cend, r1);
+        }
+        int const ncols = cend - c0;
+        if (bx * 128 >= ncols) return;
         double *X = H + (size_t)c0 * ldH + lo;
-        gemm_tile<WS_MAX, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH,
-            0, blockIdx.x);
+        gemm_tile<WS_MAX, 128, 16, true, false>(w, ncols, w, 1.0, Uk, WS_MAX, X, ldH, 0.0, X, ldH, 0, bx);
+    } else if (MODE == 1) {
+        // the rows of [0, lo) that fall into [r0, r1)
+        int const rbeg = r0, rows = min(lo, r1) - rbeg;
+        if (bx * 128 >= rows) return;
+        double *X = H + (size_t)lo * ldH + rbeg;
+        gemm_tile<128, WS_MAX, 16, false, false>(rows, w, w, 1.0, X, ldH, Uk, WS_MAX, 0.0, X, ldH, bx, 0);
     } else {
-        int const rows = is_q ? n : lo;
-        if ((int)blockIdx.x * 128 >= rows) return;
-        double *X = is_q ? Q + (size_t)lo * ldQ : H + (size_t)lo * ldH;
-        int const ld = is_q ? ldQ : ldH;
-        gemm_tile<128, WS_MAX, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, WS_MAX, 0.0, X, ld,
-            blockIdx.x, 0);
+        if (bx * 128 >= n) return;
+        double *X = Q + (size_t)lo * ldQ;
+        gemm_tile<128, WS_MAX, 16, false, false>(n, w, w, 1.0, X, ldQ, Uk, WS_MAX, 0.0, X, ldQ, bx, 0);
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U, int r0, int r1)
+{
+    schur_update_body<MODE>(step, H, ldH, Q, ldQ, n, U, r0, r1, blockIdx.x, blockIdx.y);
+}
+
+// The LAZY far-left (blockIdx.z = 0, columns [c0, c1) right of ihi) and right (blockIdx.z = 1,
+// rows [r0, r1) above the band) updates of one step in one launch -- they touch disjoint
+// columns.  (The host issues ~10^4 steps per reduction and its launch rate, not the GPU,
+// bounds the reduction when every part is a launch of its own.)
+__global__ __launch_bounds__(256, 2)
+void schur_update_pair_kernel(SweepStep const step, double *__restrict__ H, int ldH, int n,
+    double const *__restrict__ U, int c0, int c1, int r0, int r1)
+{
+    if (blockIdx.z == 0) schur_update_body<0>(step, H, ldH, nullptr, 0, n, U, c0, c1, blockIdx.x, blockIdx.y);
+    else schur_update_body<1>(step, H, ldH, nullptr, 0, n, U, r0, r1, blockIdx.x, blockIdx.y);
 }
 
 // sub[i] = H(i+1,i) for i in [lo,hi-1); entries below the threshold are set to exactly zero
@@ -226,13 +264,24 @@ struct SchurWorkspace {
     double *hWin = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
     ChaseTask *hTasks = nullptr;
     bool attr_set = false;
-    hipStream_t far = nullptr;
-    static constexpr int EV_RING = 64;
+    hipStream_t far = nullptr, qs = nullptr, hs = nullptr;    // timely far H updates; lazy Q; lazy H
+    static constexpr int EV_RING = 2048;        // = ring of per-step U buffers (the lazy streams lag a sweep)
     hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
+    static constexpr int FLUSH_RING = 16;       // lazy launches are issued in batches; one event pair per batch
+    hipEvent_t q_done[FLUSH_RING] = {}, h_done[FLUSH_RING] = {};
+    long flush_total = 0;
+    std::vector<long> slot_flush = std::vector<long>(EV_RING, -1);     // batch that consumes the U slot
+    static constexpr int Z_RING = 64;           // AED / small-block factors waiting for the lazy stream
+    double *dZq = nullptr, *dTmpQ = nullptr;
+    hipEvent_t z_ready[Z_RING] = {}, z_done[Z_RING] = {}, zh_done[Z_RING] = {};
+    double *dTmpH = nullptr;
+    long issued_total = 0, z_total = 0;
+    int guard_row = 0;          // R1: rows >= guard_row are always updated timely
+    hipEvent_t lazy_mark = nullptr;
 
     void release() {
         void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dDescs, (void **)&dShiftR, (void **)&dShiftI,
-            (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc};
+            (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc, (void **)&dZq, (void **)&dTmpQ, (void **)&dTmpH};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hTasks, (void **)&hDescs};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
@@ -242,7 +291,10 @@ struct SchurWorkspace {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
-        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * WS_MAX * WS_MAX * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)EV_RING * max_chains * WS_MAX * WS_MAX * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dZq, (size_t)Z_RING * nwmax * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dTmpH, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
@@ -257,10 +309,28 @@ struct SchurWorkspace {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
+            int lo_prio = 0, hi_prio = 0;
+            SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, lo_prio));
             for (int k = 0; k < EV_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&far_done[k], hipEventDisableTiming));
             }
+            for (int k = 0; k < FLUSH_RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&q_done[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&h_done[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
+            for (int k = 0; k < Z_RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&z_ready[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&z_done[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&zh_done[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<3>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_pair_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_P));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<2>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<0>,
@@ -300,34 +370,72 @@ struct Driver {
     SchurStats st;
     long ring_pos = 0;
 
+    // the critical stream waits until the lazy H updates issued so far are done
+    void wait_lazy_h()
+    {
+        SN_HIP_CHECK(hipEventRecord(ws.lazy_mark, ws.hs));
+        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
+    }
+
+    // Moves the guard row R1 (rows >= R1 are updated timely).  Rows that change from the lazy
+    // to the timely zone must first see the lazy updates issued so far.
+    void set_guard_row(int r1)
+    {
+        static bool const norows = getenv("SN_SCHUR_NOLAZYROWS") != nullptr;   // debugging aid
+        r1 = norows ? 0 : std::max(0, r1);
+        if (r1 < ws.guard_row) { wait_lazy_h(); prof_guard_moves++; }
+        ws.guard_row = r1;
+    }
+
+    // X(rows r0..r1 of the column block at `lo`) <- . Z   on stream st (scratch tmp for w > 128)
+    void right_update(hipStream_t st, double *M, int ldM, int r0, int r1, int lo, int w,
+        double const *dZ, int ldz, double *tmp)
+    {
+        int const rows = r1 - r0;
+        if (rows <= 0) return;
+        double *X = M + (size_t)lo * ldM + r0;
+        if (w <= 128) dgemm_right_inplace(st, rows, w, dZ, ldz, X, ldM);
+        else {
+            dgemm(st, 'N', 'N', rows, w, w, 1.0, X, ldM, dZ, ldz, 0.0, tmp, rows);
+            copy_matrix(st, rows, w, tmp, rows, X, ldM);
+        }
+    }
+
     // H(lo:lo+w, lo+w:n) <- Z^T .,  H(0:lo, lo:lo+w) <- . Z,  Q(:, lo:lo+w) <- . Z
-    // (insert_updates of schur/core.c:129-460, bodies common/cpu.c:54-162)
+    // (insert_updates of schur/core.c:129-460, bodies common/cpu.c:54-162).  The window is the
+    // trailing part of the active block, so the columns right of it belong to the deflated part:
+    // that update, the rows above the guard row and Q go to the lazy stream.
     void apply_transform(int lo, int w, double const *dZ, int ldz)
     {
         int const right_cols = n - (lo + w);
-        if (w <= 128) {
-            dgemm_left_inplace(s, w, right_cols, dZ, ldz, H + (size_t)(lo + w) * ldH + lo, ldH);
-            dgemm_right_inplace(s, lo, w, dZ, ldz, H + (size_t)lo * ldH, ldH);
-            if (Q) dgemm_right_inplace(s, n, w, dZ, ldz, Q + (size_t)lo * ldQ, ldQ);
-        } else {
-            // wider windows (AED, final small blocks): product into scratch, then copy back
-            if (right_cols > 0) {
-                double *X = H + (size_t)(lo + w) * ldH + lo;
-                // scratch is n x nwmax doubles: use it as (w x right_cols) with ld = w
-                dgemm(s, 'T', 'N', w, right_cols, w, 1.0, dZ, ldz, X, ldH, 0.0, ws.dTmp, w);
-                copy_matrix(s, w, right_cols, ws.dTmp, w, X, ldH);
-            }
-            if (lo > 0) {
-                double *X = H + (size_t)lo * ldH;
-                dgemm(s, 'N', 'N', lo, w, w, 1.0, X, ldH, dZ, ldz, 0.0, ws.dTmp, lo);
-                copy_matrix(s, lo, w, ws.dTmp, lo, X, ldH);
-            }
-            if (Q) {
-                double *X = Q + (size_t)lo * ldQ;
-                dgemm(s, 'N', 'N', n, w, w, 1.0, X, ldQ, dZ, ldz, 0.0, ws.dTmp, n);
-                copy_matrix(s, n, w, ws.dTmp, n, X, ldQ);
+        int const split = std::min(lo, ws.guard_row);
+        // timely: H(split:lo, window columns)
+        right_update(s, H, ldH, split, lo, lo, w, dZ, ldz, ws.dTmp);
+        // lazy, from a private copy of Z (the caller's buffer is reused by the next AED long
+        // before the lazy stream gets here)
+        int const slot = (int)(ws.z_total % SchurWorkspace::Z_RING);
+        double *Zc = ws.dZq + (size_t)slot * ws.nwmax * ws.nwmax;
+        if (ws.z_total >= SchurWorkspace::Z_RING) {
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.z_done[slot], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.zh_done[slot], 0));
+        }
+        copy_matrix(s, w, w, dZ, ldz, Zc, w);
+        SN_HIP_CHECK(hipEventRecord(ws.z_ready[slot], s));
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.hs, ws.z_ready[slot], 0));
+        if (right_cols > 0) {
+            double *X = H + (size_t)(lo + w) * ldH + lo;
+            if (w <= 128) dgemm_left_inplace(ws.hs, w, right_cols, Zc, w, X, ldH);
+            else {
+                dgemm(ws.hs, 'T', 'N', w, right_cols, w, 1.0, Zc, w, X, ldH, 0.0, ws.dTmpH, w);
+                copy_matrix(ws.hs, w, right_cols, ws.dTmpH, w, X, ldH);
             }
         }
+        right_update(ws.hs, H, ldH, 0, split, lo, w, Zc, w, ws.dTmpH);
+        SN_HIP_CHECK(hipEventRecord(ws.zh_done[slot], ws.hs));
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.z_ready[slot], 0));
+        if (Q) right_update(ws.qs, Q, ldQ, 0, n, lo, w, Zc, w, ws.dTmpQ);
+        SN_HIP_CHECK(hipEventRecord(ws.z_done[slot], ws.qs));
+        ws.z_total++;
         st.gemm_flops += 2.0 * w * w * ((double)right_cols + lo + (Q ? n : 0));
     }
 
@@ -337,7 +445,7 @@ struct Driver {
         SN_HIP_CHECK(hipMemcpy2DAsync(h, (size_t)ldh * 8, H + (size_t)lo * ldH + lo, (size_t)ldH * 8,
             (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
-        st.wait_s += wall() - t0;
+        st.wait_s += wall() - t0; prof_dl_wait += wall() - t0;
     }
     void upload_window(int lo, int w, double const *h, int ldh)
     {
@@ -372,6 +480,41 @@ struct Driver {
         return 0;
     }
 
+    // Lazy parts of the window steps: columns [ihi, n) of the left updates, rows [0, T0) of the
+    // right updates (each ordered behind the timely updates of its step: entries only ever move
+    // from the timely to the lazy zone within a sweep) and Q.  They are issued after the
+    // critical path of the sweep so that they execute while the host reduces the AED windows
+    // that follow, instead of competing with the sweep for the CUs.
+    double prof_scan_wait = 0, prof_dl_wait = 0, prof_issue = 0, prof_guard = 0; int prof_guard_moves = 0;
+    struct LazyItem { SweepStep step; int ev; int row_split; };
+    std::vector<LazyItem> lazy;
+    void flush_lazy(int col_split)
+    {
+        if (lazy.empty()) return;
+        // the far stream is in order: the timely updates of the last step cover all earlier ones
+        int const last_ev = lazy.back().ev;
+        int const fslot = (int)(ws.flush_total % SchurWorkspace::FLUSH_RING);
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.hs, ws.far_done[last_ev], 0));
+        if (Q) SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.near_done[last_ev], 0));
+        for (LazyItem const &it : lazy) {
+            int const ntasks = it.step.ntasks;
+            double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
+            int const lazy_cols = n - col_split, lazy_rows = it.row_split;
+            if (lazy_cols > 0 || lazy_rows > 0)
+                hipLaunchKernelGGL(schur_update_pair_kernel,
+                    dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
+                    UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
+            if (Q)
+                hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(n, 128), ntasks),
+                    dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, n, Ubuf, 0, n);
+            ws.slot_flush[it.ev] = ws.flush_total;
+        }
+        SN_HIP_CHECK(hipEventRecord(ws.h_done[fslot], ws.hs));
+        if (Q) SN_HIP_CHECK(hipEventRecord(ws.q_done[fslot], ws.qs));
+        ws.flush_total++;
+        lazy.clear();
+    }
+
     // one multi-shift sweep over the active block [ilo, ihi) with `nshifts` shifts
     void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
     {
@@ -382,6 +525,7 @@ struct Driver {
         if (nbc < 1) nbc = 1;
         if (size <= WS_MAX) nbc = std::min(nbulges, std::max(1, (size - 1) / 3));
         nbc = std::min(nbc, NB_MAX);
+        nbulges = std::min(nbulges, nbc * ws.max_chains);       // U buffers hold max_chains windows per step
         int const chains = divceil(nbulges, nbc);
         int const adv = ws_ - 1 - 3 * nbc;                    // columns a chain advances per step
         // chains ws+adv rows apart: a chain's next window then depends on its OWN near update only
@@ -397,12 +541,17 @@ struct Driver {
         int const total_steps = steps_per_chain + (chains - 1) * gap;
         SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
         // Pipeline: critical stream s:  chase(t) -> [wait far(t-1)] near(t)
-        //           far stream       :  [wait near(t)] far-left(t), right/Q(t)
-        // so chase(t+1) overlaps far(t).  U is double-buffered by step parity; chase(t+2)
-        // follows near(t+1) which waited for far(t), the last reader of its U buffer.
+        //           far stream f     :  [wait near(t)] timely far-left(t), timely right(t)
+        //           lazy streams     :  [wait far(t)] the lazy parts of far-left / right;  Q
+        // so chase(t+1) overlaps far(t).  The U factors of a step live in a ring slot until the
+        // lazy streams have consumed them.
+        // At the start of a sweep the chains are back at the top: rows that were above the band
+        // (lazy) in the previous sweep are in the band (timely) again.
+        wait_lazy_h();
         hipStream_t const f = ws.far;
-        long issued = 0;
+        long issued = 0, last_waited_flush = -1;
         int last_t = -2;
+        int const col_split = ihi;                      // columns >= ihi: deflated part, lazy
         for (int t = 0; t < total_steps; t++) {
             int cmin = (t - steps_per_chain + 1 + gap - 1) / gap;      // ceil for positives
             if (t - steps_per_chain + 1 <= 0) cmin = 0;
@@ -410,10 +559,28 @@ struct Driver {
             if (cmax < cmin) continue;
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
-            int const par = (int)(issued & 1);
-            double *Ubuf = ws.dU + (size_t)par * ws.max_chains * WS_MAX * WS_MAX;
-            int const ev = (int)(issued % SchurWorkspace::EV_RING);
-            int const evp = (int)((issued + SchurWorkspace::EV_RING - 1) % SchurWorkspace::EV_RING);
+            // U buffers and events live in a ring indexed by a counter that runs across sweeps
+            int const ev = (int)(ws.issued_total % SchurWorkspace::EV_RING);
+            int const evp = (int)((ws.issued_total + SchurWorkspace::EV_RING - 1) % SchurWorkspace::EV_RING);
+            double *Ubuf = ws.dU + (size_t)ev * ws.max_chains * WS_MAX * WS_MAX;
+            if (ws.slot_flush[ev] >= 0) {
+                // the lazy streams must be through with the previous tenant of this U slot
+                long const fid = ws.slot_flush[ev];
+                if (fid != last_waited_flush) {
+                    if (ws.flush_total - fid < SchurWorkspace::FLUSH_RING) {
+                        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.h_done[(int)(fid % SchurWorkspace::FLUSH_RING)], 0));
+                        if (Q) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.q_done[(int)(fid % SchurWorkspace::FLUSH_RING)], 0));
+                    } else {        // the batch events were recycled: wait for everything issued so far
+                        wait_lazy_h();
+                        if (Q) {
+                            SN_HIP_CHECK(hipEventRecord(ws.lazy_mark, ws.qs));
+                            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
+                        }
+                    }
+                    last_waited_flush = fid;
+                }
+                ws.slot_flush[ev] = -1;
+            }
             // chase(t) may overlap far(t-1) only in the regular regime.  On short active blocks
             // steps are skipped (a chain finishes before the next one is introduced) and the new
             // chain's first window would race with the finished chain's pending updates
@@ -422,30 +589,44 @@ struct Driver {
             hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
                 step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
-            int max_far = 0;
+            int min_lo = n, max_lo = 0;
             for (int k = 0; k < ntasks; k++) {
                 ChaseTask const tk = make_task(step, k);
                 int const rc = n - (tk.lo + tk.n);
-                max_far = std::max(max_far, rc - adv);
+                min_lo = std::min(min_lo, tk.lo); max_lo = std::max(max_lo, tk.lo);
                 st.gemm_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
             }
+            // rows above T0 are out of reach of every chain still in flight and of the AED windows
+            // that follow this sweep (guard row)
+            // (while chains are still being introduced at the top, every row is within reach)
+            int const rear = (cmax == chains - 1) ? min_lo : ilo;
+            int const row_split = std::max(0, std::min(rear, ws.guard_row));
             if (issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(schur_update_kernel<2>, dim3(1, ntasks), dim3(256),
-                UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, Ubuf);
+                UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, Ubuf, 0, n);
             SN_HIP_CHECK(hipEventRecord(ws.near_done[ev], s));
             SN_HIP_CHECK(hipStreamWaitEvent(f, ws.near_done[ev], 0));
-            if (max_far > 0)
-                hipLaunchKernelGGL(schur_update_kernel<0>, dim3(divceil(max_far, 128), ntasks), dim3(256),
-                    UPDATE_LDS_BYTES_L, f, step, H, ldH, Q, ldQ, n, Ubuf);
-            hipLaunchKernelGGL(schur_update_kernel<1>, dim3(divceil(n, 128), Q ? 2 * ntasks : ntasks),
-                dim3(256), UPDATE_LDS_BYTES_R, f, step, H, ldH, Q, ldQ, n, Ubuf);
+            // timely: columns [lo+w+adv, ihi) and rows [T0, lo).  Two launches: the left update of
+            // one chain and the right update of a chain ahead of it meet in the same entries
+            int const timely_cols = col_split - (min_lo + ws_ + adv), timely_rows = max_lo - row_split;
+            if (timely_cols > 0)
+                hipLaunchKernelGGL(schur_update_kernel<0>, dim3(divceil(timely_cols, 128), ntasks), dim3(256),
+                    UPDATE_LDS_BYTES_L, f, step, H, ldH, Q, ldQ, n, Ubuf, 0, col_split);
+            if (timely_rows > 0)
+                hipLaunchKernelGGL(schur_update_kernel<1>, dim3(divceil(timely_rows, 128), ntasks), dim3(256),
+                    UPDATE_LDS_BYTES_R, f, step, H, ldH, Q, ldQ, n, Ubuf, row_split, n);
             SN_HIP_CHECK(hipEventRecord(ws.far_done[ev], f));
+            // the lazy parts of this step are issued when the sweep is through (see flush_lazy)
+            lazy.push_back(LazyItem{step, ev, row_split});
+            if ((int)lazy.size() >= SchurWorkspace::EV_RING / 2) flush_lazy(col_split);
             issued++;
+            ws.issued_total++;
             last_t = t;
         }
         // the sweep is complete when the far stream has drained
         if (issued > 0)
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((issued - 1) % SchurWorkspace::EV_RING)], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % SchurWorkspace::EV_RING)], 0));
+        flush_lazy(col_split);
         st.sweeps++;
     }
 };
@@ -495,7 +676,8 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // sweep and cut the number of sweeps at n = 20000 from 81 to 13 (measured: 7.0 s -> 5.4 s at
     // a 192-row AED window).
     static int const reuse = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 8;
-    ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
+    ws.ensure(n, wmax, divceil(reuse * (ns_conf / 2), NB_MAX) + 2);
+    ws.guard_row = 0;
     Driver d{s, n, dH, ldH, dQ, ldQ, ws, SchurStats{}};
 
     hipEvent_t e0, e1;
@@ -526,7 +708,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             double tw = wall();
             SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
             SN_HIP_CHECK(hipStreamSynchronize(s));
-            d.st.wait_s += wall() - tw;
+            d.st.wait_s += wall() - tw; d.prof_scan_wait += wall() - tw;
         }
         int ilo = ihi - 1;
         while (ilo > 0 && ws.hSub[ilo - 1] != 0.0) ilo--;
@@ -539,6 +721,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             ihi = ilo; continue;
         }
         if (size <= small_limit) {
+            if (ilo < ws.guard_row) d.set_guard_row(ilo);
             int info = d.small_block(ilo, size, real, imag);
             if (info != 0) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
             ihi = ilo; stagnation = 0; continue;
@@ -552,6 +735,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         double sub = 0.0;
         if (kw > ilo) sub = ws.hSub[kw - 1];
         int const ldh = Driver::host_ld(nw);
+        if (kw < ws.guard_row) d.set_guard_row(kw - 4 * nw);
         d.download_window(kw, nw, ws.hWin, ldh);
         double t_aed0 = wall();
         host::AedResult ar = host::aed_window(nw, ws.hWin, ldh, ws.hZ, ldh, sub, thres,
@@ -621,14 +805,26 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
                 for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
             nshifts *= reuse;
         }
+        // rows below the guard row stay timely: room for the AED windows that follow the sweep
+        d.set_guard_row(ihi - 8 * nw_conf);
+        double const t_issue = wall();
         d.sweep(ilo, ihi, nshifts, sr.data(), si.data());
+        d.prof_issue += wall() - t_issue;
         iter++;
     }
+    // the lazy streams have to drain before the result is complete
+    SN_HIP_CHECK(hipEventRecord(ws.lazy_mark, ws.hs));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
+    SN_HIP_CHECK(hipEventRecord(fence, ws.qs));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, fence, 0));
     SN_HIP_CHECK(hipEventRecord(e1, s));
     SN_HIP_CHECK(hipStreamWaitEvent(caller, e1, 0));
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
+    if (getenv("SN_SCHUR_PROFILE"))
+        fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d\n",
+            d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves);
     if (stats) *stats = d.st;
     return rc;
 }
