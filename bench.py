@@ -6,7 +6,8 @@
 One "step" = Hessenberg reduction + Schur reduction (Q accumulated through both) of one
 synthetic n x n matrix (the reference test driver's LCG input, seed 2019, generated
 directly in HBM; Q = I), inputs resident in HBM when the timed region starts.
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  `--workload qz` measures BASELINE config 5 instead (QZ of
+a 12000 x 12000 Hessenberg-triangular pencil); it is not the headline metric.
 
 At N > 1 the N GPUs reduce ONE matrix together (strong scaling): the Hessenberg leg is
 sharded by block column (per-column all-reduce of the partial y = A v, panel broadcast,
@@ -44,6 +45,55 @@ def schur_flops(n):
     return 25.0 * n ** 3            # Golub & Van Loan convention
 
 
+def qz_flops(n):
+    return 66.0 * n ** 3            # Golub & Van Loan QZ with Q and Z
+
+
+def bench_qz(args):
+    """BASELINE config 5 (not the headline metric): generalized Schur (QZ) reduction of the
+    reference test driver's random Hessenberg-triangular pencil, n = 12000 by default, Q = Z = I,
+    device resident.  Prints one JSON line of the same shape."""
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import starneig_amd as S
+    S.node_init(1, 1, S.NO_MESSAGES)
+    n = args.n if args.n != 20000 else 12000
+    tH0, tR0 = S.device_matrix(n), S.device_matrix(n)
+    assert S.lcg_pencil_device(tH0, tR0, n, seed=2019) == 0
+    tQ, tZ = S.device_matrix(n), S.device_matrix(n)
+    times, st = [], None
+    for it in range(args.warmup + args.steps):
+        tH, tR = tH0.clone(), tR0.clone()
+        S.set_matrix_device(tQ, n, n, 0.0, 1.0); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc, ar, ai, be, st = S.gep_schur_device(tH, tR, tQ, tZ, n=n)
+        torch.cuda.synchronize()
+        assert rc == 0, f"gep schur rc={rc}"
+        if it >= args.warmup:
+            times.append(time.perf_counter() - t0)
+    _, ca = S.check_pencil_device(tQ, tH, tZ, tH0, n=n)
+    _, cb = S.check_pencil_device(tQ, tR, tZ, tR0, n=n)
+    total = sum(times)
+    print(json.dumps({
+        "metric": "GFLOP/s generalized Schur (QZ), n=12000 Hessenberg-triangular pencil, 1 MI355X",
+        "value": args.steps * qz_flops(n) / total / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"QZ, n={n}, Q and Z accumulated, LCG pencil seed 2019 (BASELINE config 5); "
+                               f"value = 66 n^3 flop / time",
+                   "n": n, "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
+                   "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
+                   "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
+                   "qz_sweeps": st["sweeps"], "aeds": st["aeds"],
+                   "executed_gemm_tflop_per_step": st["gemm_flops"] / 1e12,
+                   "aed_host_s": st["aed_host_s"]},
+    }), flush=True)
+    S.node_finalize()
+
+
 def cpu_baseline(n_sample):
     """The CPU oracle (kind "port": the restatement of the reference algorithm) timed on
     this host's cores on a bounded sample of the same workload (smaller n, same input
@@ -78,9 +128,13 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=1500, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded Hessenberg path even at N=1 (exercises the collectives)")
+    ap.add_argument("--workload", choices=["sep", "qz"], default="sep",
+                    help="sep = Hessenberg + Schur (the headline metric); qz = BASELINE config 5")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
+    if args.workload == "qz":
+        return bench_qz(args)
 
     import torch
     import torch.distributed as dist
