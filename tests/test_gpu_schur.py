@@ -204,3 +204,37 @@ def test_special_matrices_converge(node, name):
     if nrm > 0:
         assert np.linalg.norm(Q @ H @ Q.T - H0) / nrm < WARN_U * U
     assert np.linalg.norm(Q @ Q.T - np.eye(n)) / np.sqrt(n) < WARN_U * U
+
+
+@pytest.mark.parametrize("n,conf_vals", [(3500, None), (5000, (96, 60, 128)), (4000, (200, 120, 256))])
+def test_device_resident_chain_exercises_update_zones(node, n, conf_vals):
+    """Sizes beyond 8 AED windows: rows above the chain band and above the guard row, the
+    deflated columns and Q are updated on the lazy streams; the device-resident
+    chain must still pass the reference's acceptance checks and reproduce itself bit for bit
+    (the zones only reorder commuting updates; a race would show up as run-to-run differences
+    in H -- Q and H are compared after an identical Hessenberg input)."""
+    import torch
+    tA0 = node.device_matrix(n)
+    assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
+    tH0 = tA0.clone(); tQ0 = node.device_matrix(n)
+    node.set_matrix_device(tQ0, n, n, 0.0, 1.0)
+    assert node.hessenberg_device(tH0, tQ0, n=n) == 0
+    conf = None
+    if conf_vals:
+        conf = node.schur_init_conf()
+        conf.aed_window_size, conf.shift_count, conf.small_limit = conf_vals
+    results = []
+    for rep in range(2):
+        tH, tQ = tH0.clone(), tQ0.clone()
+        rc, real, imag, st = node.schur_device(tH, tQ, n=n, conf=conf)
+        torch.cuda.synchronize()
+        assert rc == 0 and st["sweeps"] > 0
+        rc, chk = node.check_device(tQ, tH, tA0, n=n)
+        assert rc == 0
+        assert chk["residual_u"] < WARN_U and chk["orthogonality_u"] < WARN_U
+        assert chk["below_subdiagonal"] == 0
+        results.append((tH, tQ, real, imag))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+    S = to_host(results[0][0])
+    assert O.check_schur_form(S) == 0
+    assert abs(results[0][2].sum() - float(torch.diagonal(tA0[:, :n]).sum())) <= 1e-9 * n
