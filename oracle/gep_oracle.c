@@ -153,7 +153,9 @@ static int standardise(int n, int k, double *A, int lda, double *B, int ldb,
         double c, s, zx, zy;
         if (p != 0.0) {
             double sq = sqrt(disc);
-            double l = (q >= 0.0) ? (q + sq)/(2.0*p) : (q - sq)/(2.0*p);   /* larger root: stable */
+            /* the root of smaller magnitude, without cancellation: 2r / (q + sign(q) sqrt(disc)) */
+            double den = (q >= 0.0) ? (q + sq) : (q - sq);
+            double l = (den != 0.0) ? 2.0*r/den : 0.0;
             double c11 = a11 - l*b11, c12 = a12 - l*b12, c21 = a21, c22 = a22 - l*b22;
             /* null vector from the row of larger norm */
             if (fabs(c11) + fabs(c12) >= fabs(c21) + fabs(c22)) { zx = c12; zy = -c11; }

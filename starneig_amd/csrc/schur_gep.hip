@@ -202,7 +202,8 @@ void gep_chase_kernel(SweepStep const step, double *__restrict__ Ag, int ldA,
 // Off-diagonal updates of all chains of one step, A and B in one launch.
 //   MODE 2 ("near"): X(win, next `adv` columns) <- Uq^T .      X in {A, B}
 //   MODE 0 ("far") : the remaining columns right of the window
-//   MODE 1         : X(above win, win) <- . Uz  (X in {A, B}),  Q(:, win) <- . Uq,  Z(:, win) <- . Uz
+//   MODE 1         : X(above win, win) <- . Uz  (X in {A, B})
+//   MODE 3         : Q(:, win) <- . Uq,  Z(:, win) <- . Uz   (lazy stream)
 template <int MODE>
 __global__ __launch_bounds__(256, 2)
 void gep_update_kernel(SweepStep const step, double *__restrict__ A, int ldA,
@@ -221,16 +222,22 @@ void gep_update_kernel(SweepStep const step, double *__restrict__ A, int ldA,
         int const ld = which ? ldB : ldA;
         double *X = (which ? B : A) + (size_t)c0 * ld + lo;
         gemm_tile<64, 128, 16, true, false>(w, ncols, w, 1.0, Uq, GWS, X, ld, 0.0, X, ld, 0, blockIdx.x);
-    } else {
-        // which: 0 = A, 1 = B, 2 = Z, 3 = Q   (Q/Z slots are launched only when present)
-        double *X; int ld, rows; double const *Uk = Uz;
-        if (which == 0) { X = A; ld = ldA; rows = lo; }
-        else if (which == 1) { X = B; ld = ldB; rows = lo; }
-        else if (which == 2 && Z) { X = Z; ld = ldZ; rows = n; }
-        else { X = Q; ld = ldQ; rows = n; Uk = Uq; }
-        if (X == nullptr || (int)blockIdx.x * 128 >= rows) return;
+    } else if (MODE == 1) {
+        // which: 0 = A, 1 = B
+        double *X = which ? B : A;
+        int const ld = which ? ldB : ldA, rows = lo;
+        if ((int)blockIdx.x * 128 >= rows) return;
         X += (size_t)lo * ld;
-        gemm_tile<128, 64, 16, false, false>(rows, w, w, 1.0, X, ld, Uk, GWS, 0.0, X, ld, blockIdx.x, 0);
+        gemm_tile<128, 64, 16, false, false>(rows, w, w, 1.0, X, ld, Uz, GWS, 0.0, X, ld, blockIdx.x, 0);
+    } else {
+        // MODE 3 -- which: 0 = Z (or Q when there is no Z), 1 = Q.  Nothing on the GPU reads
+        // Q or Z: these run on the lazy stream (see schur.hip)
+        double *X; int ld; double const *Uk = Uz;
+        if (which == 0 && Z) { X = Z; ld = ldZ; }
+        else { X = Q; ld = ldQ; Uk = Uq; }
+        if (X == nullptr || (int)blockIdx.x * 128 >= n) return;
+        X += (size_t)lo * ld;
+        gemm_tile<128, 64, 16, false, false>(n, w, w, 1.0, X, ld, Uk, GWS, 0.0, X, ld, blockIdx.x, 0);
     }
 }
 
@@ -256,18 +263,27 @@ __global__ void gep_set_entry_kernel(double *p, double v) { *p = v; }
 // ---- workspace --------------------------------------------------------------------------
 struct GepWorkspace {
     int n = 0, nwmax = 0, max_chains = 0;
-    double *dU = nullptr;           // 2 (parity) x max_chains x {Uq, Uz} x GWS x GWS
+    double *dU = nullptr;           // EV_RING x max_chains x {Uq, Uz} x GWS x GWS
     double *dShiftR = nullptr, *dShiftI = nullptr, *dSub = nullptr;
     double *dQl = nullptr, *dZl = nullptr, *dTmp = nullptr, *dAcc = nullptr;
     double *hA = nullptr, *hB = nullptr, *hQ = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
     bool attr_set = false;
-    hipStream_t far = nullptr;
-    static constexpr int EV_RING = 64;
+    hipStream_t far = nullptr, qs = nullptr;    // far updates of A, B; lazy updates of Q, Z
+    static constexpr int EV_RING = 2048;        // ring of per-step factor buffers
     hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
+    static constexpr int FLUSH_RING = 16;
+    hipEvent_t q_done[FLUSH_RING] = {};
+    long issued_total = 0, flush_total = 0;
+    std::vector<long> slot_flush = std::vector<long>(EV_RING, -1);
+    static constexpr int Z_RING = 64;           // AED / small-block factors waiting for the lazy stream
+    double *dQZq = nullptr, *dTmpQ = nullptr;   // Z_RING x {Ql, Zl}; scratch of the lazy stream
+    hipEvent_t z_ready[Z_RING] = {}, z_done[Z_RING] = {};
+    long z_total = 0;
+    hipEvent_t lazy_mark = nullptr;
 
     void release() {
         void **dptrs[] = {(void **)&dU, (void **)&dShiftR, (void **)&dShiftI, (void **)&dSub,
-            (void **)&dQl, (void **)&dZl, (void **)&dTmp, (void **)&dAcc};
+            (void **)&dQl, (void **)&dZl, (void **)&dTmp, (void **)&dAcc, (void **)&dQZq, (void **)&dTmpQ};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         void **hptrs[] = {(void **)&hA, (void **)&hB, (void **)&hQ, (void **)&hZ, (void **)&hSub};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
@@ -278,7 +294,9 @@ struct GepWorkspace {
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
         size_t const w2 = (size_t)(nwmax + 8) * nwmax * 8;
-        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)2 * max_chains * 2 * GWS * GWS * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)EV_RING * max_chains * 2 * GWS * GWS * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dQZq, (size_t)Z_RING * 2 * nwmax * nwmax * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
@@ -295,6 +313,17 @@ struct GepWorkspace {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, GEP_CHASE_LDS_BYTES));
             SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
+            int lo_prio = 0, hi_prio = 0;
+            SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
+            SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
+            for (int k = 0; k < FLUSH_RING; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&q_done[k], hipEventDisableTiming));
+            for (int k = 0; k < Z_RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&z_ready[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&z_done[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_update_kernel<3>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, GEP_LDS_BYTES_R));
             for (int k = 0; k < EV_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&far_done[k], hipEventDisableTiming));
@@ -347,15 +376,35 @@ struct GepDriver {
             copy_matrix(s, rows, w, ws.dTmp, rows, P, ld);
         }
     }
-    // (A,B)(win, right) <- Ql^T .,  (A,B)(above, win) <- . Zl,  Q(:,win) <- . Ql,  Z(:,win) <- . Zl
+    // (A,B)(win, right) <- Ql^T .,  (A,B)(above, win) <- . Zl,  Q(:,win) <- . Ql,  Z(:,win) <- . Zl.
+    // Q and Z are updated on the lazy stream from private copies of the factors.
     void apply_transform(int lo, int w, double const *dQl, double const *dZl, int ldu)
     {
         left_update(A, ldA, lo, w, dQl, ldu);
         left_update(B, ldB, lo, w, dQl, ldu);
         right_update(A, ldA, lo, lo, w, dZl, ldu);
         right_update(B, ldB, lo, lo, w, dZl, ldu);
-        if (Q) right_update(Q, ldQ, n, lo, w, dQl, ldu);
-        if (Z) right_update(Z, ldZ, n, lo, w, dZl, ldu);
+        if (Q || Z) {
+            int const slot = (int)(ws.z_total % GepWorkspace::Z_RING);
+            double *Qc = ws.dQZq + (size_t)slot * 2 * ws.nwmax * ws.nwmax, *Zc = Qc + (size_t)ws.nwmax * ws.nwmax;
+            if (ws.z_total >= GepWorkspace::Z_RING) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.z_done[slot], 0));
+            copy_matrix(s, w, w, dQl, ldu, Qc, w);
+            copy_matrix(s, w, w, dZl, ldu, Zc, w);
+            SN_HIP_CHECK(hipEventRecord(ws.z_ready[slot], s));
+            SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.z_ready[slot], 0));
+            auto lazy_right = [&](double *X, int ld, double const *U) {
+                double *P = X + (size_t)lo * ld;
+                if (w <= 128) dgemm_right_inplace(ws.qs, n, w, U, w, P, ld);
+                else {
+                    dgemm(ws.qs, 'N', 'N', n, w, w, 1.0, P, ld, U, w, 0.0, ws.dTmpQ, n);
+                    copy_matrix(ws.qs, n, w, ws.dTmpQ, n, P, ld);
+                }
+            };
+            if (Q) lazy_right(Q, ldQ, Qc);
+            if (Z) lazy_right(Z, ldZ, Zc);
+            SN_HIP_CHECK(hipEventRecord(ws.z_done[slot], ws.qs));
+            ws.z_total++;
+        }
         st.gemm_flops += 2.0 * w * w * (2.0 * (n - lo - w) + 2.0 * lo + (Q ? n : 0) + (Z ? n : 0));
     }
 
@@ -401,6 +450,27 @@ struct GepDriver {
         return 0;
     }
 
+    // Q and Z updates of the window steps: issued after the sweep's critical path, on the lazy
+    // stream, so that they execute while the host reduces the AED windows that follow
+    struct LazyItem { SweepStep step; int ev; };
+    std::vector<LazyItem> lazy;
+    void flush_lazy()
+    {
+        if (lazy.empty()) return;
+        int const qz = (Q ? 1 : 0) + (Z ? 1 : 0);
+        int const fslot = (int)(ws.flush_total % GepWorkspace::FLUSH_RING);
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.near_done[lazy.back().ev], 0));
+        for (LazyItem const &it : lazy) {
+            double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * 2 * GWS * GWS;
+            hipLaunchKernelGGL(gep_update_kernel<3>, dim3(divceil(n, 128), qz * it.step.ntasks), dim3(256),
+                GEP_LDS_BYTES_R, ws.qs, it.step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
+            ws.slot_flush[it.ev] = ws.flush_total;
+        }
+        SN_HIP_CHECK(hipEventRecord(ws.q_done[fslot], ws.qs));
+        ws.flush_total++;
+        lazy.clear();
+    }
+
     // one multi-shift QZ sweep over the active block [ilo, ihi); same schedule as schur.hip
     void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
     {
@@ -420,7 +490,7 @@ struct GepDriver {
         int const total_steps = steps_per_chain + (chains - 1) * gap;
         SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
         hipStream_t const f = ws.far;
-        long issued = 0;
+        long issued = 0, last_waited_flush = -1;
         int last_t = -2;
         int const qz = (Q ? 1 : 0) + (Z ? 1 : 0);
         for (int t = 0; t < total_steps; t++) {
@@ -430,21 +500,35 @@ struct GepDriver {
             if (cmax < cmin) continue;
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
-            int const par = (int)(issued & 1);
-            double *Ubuf = ws.dU + (size_t)par * ws.max_chains * 2 * GWS * GWS;
-            int const ev = (int)(issued % GepWorkspace::EV_RING);
-            int const evp = (int)((issued + GepWorkspace::EV_RING - 1) % GepWorkspace::EV_RING);
+            // factor buffers and events live in a ring that runs across sweeps (schur.hip)
+            int const ev = (int)(ws.issued_total % GepWorkspace::EV_RING);
+            int const evp = (int)((ws.issued_total + GepWorkspace::EV_RING - 1) % GepWorkspace::EV_RING);
+            double *Ubuf = ws.dU + (size_t)ev * ws.max_chains * 2 * GWS * GWS;
+            if (ws.slot_flush[ev] >= 0) {
+                long const fid = ws.slot_flush[ev];
+                if (fid != last_waited_flush) {
+                    if (ws.flush_total - fid < GepWorkspace::FLUSH_RING)
+                        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.q_done[(int)(fid % GepWorkspace::FLUSH_RING)], 0));
+                    else {
+                        SN_HIP_CHECK(hipEventRecord(ws.lazy_mark, ws.qs));
+                        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
+                    }
+                    last_waited_flush = fid;
+                }
+                ws.slot_flush[ev] = -1;
+            }
             // see schur.hip (and tests/test_schur_pipeline.py) for the two wait rules
             static bool const serial = getenv("SN_GEP_SERIAL") != nullptr;     // debugging aid
             if (issued > 0 && (serial || last_t != t - 1)) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(gep_chase_kernel, dim3(ntasks), dim3(GEP_CHASE_THREADS), GEP_CHASE_LDS_BYTES, s,
                 step, A, ldA, B, ldB, Ubuf, ws.dShiftR, ws.dShiftI);
             st.chase_launches++;
-            int max_far = 0;
+            int max_far = 0, max_lo = 0;
             for (int k = 0; k < ntasks; k++) {
                 ChaseTask const tk = make_task(step, k);
                 int const rc = n - (tk.lo + tk.n);
                 max_far = std::max(max_far, rc - adv);
+                max_lo = std::max(max_lo, tk.lo);
                 st.gemm_flops += 2.0 * tk.n * tk.n * (2.0 * rc + 2.0 * tk.lo + (double)qz * n);
             }
             if (issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
@@ -455,14 +539,19 @@ struct GepDriver {
             if (max_far > 0)
                 hipLaunchKernelGGL(gep_update_kernel<0>, dim3(divceil(max_far, 128), 2 * ntasks), dim3(256),
                     GEP_LDS_BYTES_L, f, step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
-            hipLaunchKernelGGL(gep_update_kernel<1>, dim3(divceil(n, 128), (2 + qz) * ntasks), dim3(256),
-                GEP_LDS_BYTES_R, f, step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
+            if (max_lo > 0)
+                hipLaunchKernelGGL(gep_update_kernel<1>, dim3(divceil(max_lo, 128), 2 * ntasks), dim3(256),
+                    GEP_LDS_BYTES_R, f, step, A, ldA, B, ldB, Q, ldQ, Z, ldZ, n, Ubuf);
             SN_HIP_CHECK(hipEventRecord(ws.far_done[ev], f));
+            if (qz) lazy.push_back(LazyItem{step, ev});
             issued++;
+            ws.issued_total++;
             last_t = t;
+            if ((int)lazy.size() >= GepWorkspace::EV_RING / 2) flush_lazy();
         }
         if (issued > 0)
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((issued - 1) % GepWorkspace::EV_RING)], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % GepWorkspace::EV_RING)], 0));
+        flush_lazy();
         st.sweeps++;
     }
 };
@@ -609,6 +698,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         d.sweep(ilo, ihi, nshifts, sr.data(), si.data());
         iter++;
     }
+    SN_HIP_CHECK(hipEventRecord(fence, ws.qs));         // the lazy stream has to drain
+    SN_HIP_CHECK(hipStreamWaitEvent(s, fence, 0));
     SN_HIP_CHECK(hipEventRecord(e1, s));
     SN_HIP_CHECK(hipStreamWaitEvent(caller, e1, 0));
     SN_HIP_CHECK(hipEventSynchronize(e1));

@@ -137,10 +137,12 @@ static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
         pencil2_sum_prod(a11, a12, a21, a22, b11, b12, b22, sum, prod);
         double disc = 0.25 * sum * sum - prod;
         if (!(disc >= 0.0)) break;
-        // real pair: lambda closer to a22/b22 first
+        // real pair: deflate the eigenvalue of SMALLER magnitude (computed without cancellation
+        // as prod / larger root).  With a nearly singular B block the other one is ~1/u and
+        // A - lam B would be dominated by lam B, losing the null vector
         double rt = std::sqrt(disc);
-        double l1 = 0.5 * sum + rt, l2 = 0.5 * sum - rt;
-        double lam = (std::fabs(l1 - a22 / b22) <= std::fabs(l2 - a22 / b22)) ? l1 : l2;
+        double l_big = 0.5 * sum + (sum >= 0.0 ? rt : -rt);
+        double lam = (l_big != 0.0) ? prod / l_big : 0.0;
         // right null vector x of M = A22 - lam B22
         double m00 = a11 - lam * b11, m01 = a12 - lam * b12, m10 = a21, m11 = a22 - lam * b22;
         double x0, x1;
