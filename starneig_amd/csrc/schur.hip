@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <starneig/error.h>
 
 namespace sn {
@@ -261,10 +262,13 @@ struct SchurWorkspace {
     double *dSub = nullptr;         // n
     double *dWin = nullptr, *dZ = nullptr, *dTmp = nullptr;   // nwmax^2, nwmax^2, n*nwmax
     double *dAcc = nullptr;
-    double *hWin = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
+    double *hWin = nullptr, *hZ = nullptr, *hSub = nullptr, *hShift = nullptr;   // pinned
+    long shift_uploads = 0;
     ChaseTask *hTasks = nullptr;
     bool attr_set = false;
     hipStream_t far = nullptr, qs = nullptr, hs = nullptr;    // timely far H updates; lazy Q; lazy H
+    hipStream_t aed = nullptr;      // window traffic and timely AED updates while a sweep head is in flight
+    hipEvent_t aed_mark = nullptr;
     static constexpr int EV_RING = 2048;        // = ring of per-step U buffers (the lazy streams lag a sweep)
     hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
     static constexpr int FLUSH_RING = 16;       // lazy launches are issued in batches; one event pair per batch
@@ -283,7 +287,7 @@ struct SchurWorkspace {
         void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dDescs, (void **)&dShiftR, (void **)&dShiftI,
             (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc, (void **)&dZq, (void **)&dTmpQ, (void **)&dTmpH};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
-        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hTasks, (void **)&hDescs};
+        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hShift, (void **)&hTasks, (void **)&hDescs};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
         n = nwmax = max_chains = 0;
     }
@@ -305,6 +309,7 @@ struct SchurWorkspace {
         SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hShift, (size_t)4 * 8 * nwmax * 8, hipHostMallocDefault));
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
@@ -322,6 +327,8 @@ struct SchurWorkspace {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&h_done[k], hipEventDisableTiming));
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
+            SN_HIP_CHECK(hipStreamCreateWithFlags(&aed, hipStreamNonBlocking));
+            SN_HIP_CHECK(hipEventCreateWithFlags(&aed_mark, hipEventDisableTiming));
             for (int k = 0; k < Z_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&z_ready[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&z_done[k], hipEventDisableTiming));
@@ -368,7 +375,9 @@ struct Driver {
     int n; double *H; int ldH; double *Q; int ldQ;
     SchurWorkspace &ws;
     SchurStats st;
-    long ring_pos = 0;
+    // stream of the window downloads/uploads and of the timely AED / small-block updates: the
+    // critical stream, or the AED stream while the head of the next sweep is in flight on s
+    hipStream_t ts = nullptr;
 
     // the critical stream waits until the lazy H updates issued so far are done
     void wait_lazy_h()
@@ -410,17 +419,17 @@ struct Driver {
         int const right_cols = n - (lo + w);
         int const split = std::min(lo, ws.guard_row);
         // timely: H(split:lo, window columns)
-        right_update(s, H, ldH, split, lo, lo, w, dZ, ldz, ws.dTmp);
+        right_update(ts, H, ldH, split, lo, lo, w, dZ, ldz, ws.dTmp);
         // lazy, from a private copy of Z (the caller's buffer is reused by the next AED long
         // before the lazy stream gets here)
         int const slot = (int)(ws.z_total % SchurWorkspace::Z_RING);
         double *Zc = ws.dZq + (size_t)slot * ws.nwmax * ws.nwmax;
         if (ws.z_total >= SchurWorkspace::Z_RING) {
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.z_done[slot], 0));
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.zh_done[slot], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(ts, ws.z_done[slot], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(ts, ws.zh_done[slot], 0));
         }
-        copy_matrix(s, w, w, dZ, ldz, Zc, w);
-        SN_HIP_CHECK(hipEventRecord(ws.z_ready[slot], s));
+        copy_matrix(ts, w, w, dZ, ldz, Zc, w);
+        SN_HIP_CHECK(hipEventRecord(ws.z_ready[slot], ts));
         SN_HIP_CHECK(hipStreamWaitEvent(ws.hs, ws.z_ready[slot], 0));
         if (right_cols > 0) {
             double *X = H + (size_t)(lo + w) * ldH + lo;
@@ -443,19 +452,19 @@ struct Driver {
     {
         double t0 = wall();
         SN_HIP_CHECK(hipMemcpy2DAsync(h, (size_t)ldh * 8, H + (size_t)lo * ldH + lo, (size_t)ldH * 8,
-            (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
-        SN_HIP_CHECK(hipStreamSynchronize(s));
+            (size_t)w * 8, w, hipMemcpyDeviceToHost, ts));
+        SN_HIP_CHECK(hipStreamSynchronize(ts));
         st.wait_s += wall() - t0; prof_dl_wait += wall() - t0;
     }
     void upload_window(int lo, int w, double const *h, int ldh)
     {
         SN_HIP_CHECK(hipMemcpy2DAsync(H + (size_t)lo * ldH + lo, (size_t)ldH * 8, h, (size_t)ldh * 8,
-            (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+            (size_t)w * 8, w, hipMemcpyHostToDevice, ts));
     }
     void upload_matrix(double *d, double const *h, int ldh, int w)
     {
         SN_HIP_CHECK(hipMemcpy2DAsync(d, (size_t)w * 8, h, (size_t)ldh * 8, (size_t)w * 8, w,
-            hipMemcpyHostToDevice, s));
+            hipMemcpyHostToDevice, ts));
     }
     // host copies of a window use a padded leading dimension: w*8 bytes is a multiple of 512 for
     // the usual window sizes and the row walks of the sequential kernels would hit a handful
@@ -474,7 +483,7 @@ struct Driver {
         upload_window(lo, w, ws.hWin, ldh);
         upload_matrix(ws.dZ, ws.hZ, ldh, w);
         apply_transform(lo, w, ws.dZ, w);
-        SN_HIP_CHECK(hipStreamSynchronize(s));      // host buffers are reused
+        SN_HIP_CHECK(hipStreamSynchronize(ts));     // host buffers are reused
         if (real) for (int i = 0; i < w; i++) { real[lo + i] = wr[i]; imag[lo + i] = wi[i]; }
         st.small_solves++;
         return 0;
@@ -515,8 +524,23 @@ struct Driver {
         lazy.clear();
     }
 
-    // one multi-shift sweep over the active block [ilo, ihi) with `nshifts` shifts
-    void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
+    // ---- one multi-shift sweep over the active block [ilo, ihi), issued in up to two phases ----
+    // sweep_begin fixes the chains; sweep_issue(limit) issues window steps while the leading
+    // chain (window + near strip) stays above row `limit`; sweep_finish() runs the rest down to
+    // the (possibly smaller) ihi of that moment.  Phase A / phase B of the look-ahead scheme in
+    // schur_device: the head of a sweep runs while the host still reduces AED windows at the
+    // bottom of the block.
+    struct SweepState {
+        bool active = false;
+        int ilo = 0, ihi = 0, ws_ = 0, nbc = 0, adv = 0, gap = 1, nbulges = 0, chains = 0;
+        int t = 0, last_t = -2;
+        long issued = 0, last_waited_flush = -1;
+        int col_split = 0;          // columns >= col_split are lazy for the steps being issued
+    } sw;
+    double sweep_flops = 0.0; int sweep_launches = 0;
+    int lazy_batch = getenv("SN_SCHUR_LAZY_BATCH") ? atoi(getenv("SN_SCHUR_LAZY_BATCH")) : 32;
+
+    void sweep_begin(int ilo, int ihi, int nshifts, double const *sr, double const *si)
     {
         int const size = ihi - ilo;
         int nbulges = nshifts / 2;
@@ -526,37 +550,55 @@ struct Driver {
         if (size <= WS_MAX) nbc = std::min(nbulges, std::max(1, (size - 1) / 3));
         nbc = std::min(nbc, NB_MAX);
         nbulges = std::min(nbulges, nbc * ws.max_chains);       // U buffers hold max_chains windows per step
-        int const chains = divceil(nbulges, nbc);
-        int const adv = ws_ - 1 - 3 * nbc;                    // columns a chain advances per step
+        sw = SweepState{};
+        sw.active = true;
+        sw.ilo = ilo; sw.ihi = ihi; sw.ws_ = ws_; sw.nbc = nbc; sw.nbulges = nbulges;
+        sw.chains = divceil(nbulges, nbc);
+        sw.adv = ws_ - 1 - 3 * nbc;                           // columns a chain advances per step
         // chains ws+adv rows apart: a chain's next window then depends on its OWN near update only
-        int const gap = (adv > 0) ? divceil(ws_ + adv, adv) : 1;
-        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftR, sr, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
-        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftI, si, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
-
-        // positions of a chain: p = 0 introduce at ilo, then lo = ilo + p*adv until the window
-        // reaches ihi (finalize).  Single-window blocks run in FULL mode.
-        int steps_per_chain;
-        if (size <= WS_MAX) steps_per_chain = 1;
-        else steps_per_chain = divceil(size - ws_, adv) + 1;
-        int const total_steps = steps_per_chain + (chains - 1) * gap;
-        SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbulges, steps_per_chain, 0, 0, 0};
-        // Pipeline: critical stream s:  chase(t) -> [wait far(t-1)] near(t)
-        //           far stream f     :  [wait near(t)] timely far-left(t), timely right(t)
-        //           lazy streams     :  [wait far(t)] the lazy parts of far-left / right;  Q
-        // so chase(t+1) overlaps far(t).  The U factors of a step live in a ring slot until the
-        // lazy streams have consumed them.
+        sw.gap = (sw.adv > 0) ? divceil(ws_ + sw.adv, sw.adv) : 1;
+        sw.col_split = ihi;
+        // the caller's arrays are reused by the next AED at once: stage the shifts in pinned memory
+        // (two alternating buffers: the previous sweep's upload is long done when its buffer returns)
+        double *stage = ws.hShift + (size_t)(ws.shift_uploads++ & 1) * 2 * 8 * ws.nwmax;
+        std::memcpy(stage, sr, (size_t)nshifts * 8);
+        std::memcpy(stage + 8 * ws.nwmax, si, (size_t)nshifts * 8);
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftR, stage, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpyAsync(ws.dShiftI, stage + 8 * ws.nwmax, (size_t)nshifts * 8, hipMemcpyHostToDevice, s));
         // At the start of a sweep the chains are back at the top: rows that were above the band
         // (lazy) in the previous sweep are in the band (timely) again.
         wait_lazy_h();
+    }
+
+    // positions of a chain: p = 0 introduce at ilo, then lo = ilo + p*adv until the window
+    // reaches ihi (finalize).  Single-window blocks run in FULL mode.
+    int steps_per_chain() const
+    {
+        int const size = sw.ihi - sw.ilo;
+        return (size <= WS_MAX) ? 1 : divceil(size - sw.ws_, sw.adv) + 1;
+    }
+
+    // Pipeline: critical stream s:  chase(t) -> [wait far(t-1)] near(t)
+    //           far stream f     :  [wait near(t)] timely far-left(t), timely right(t)
+    //           lazy streams     :  the lazy parts of far-left / right;  Q  (flush_lazy)
+    // so chase(t+1) overlaps far(t).  The U factors of a step live in a ring slot until the
+    // lazy streams have consumed them.  Returns true when the sweep is complete.
+    bool sweep_issue(int limit)
+    {
+        int const ilo = sw.ilo, ihi = sw.ihi, ws_ = sw.ws_, adv = sw.adv, gap = sw.gap, chains = sw.chains;
+        int const spc = steps_per_chain();
+        int const total_steps = spc + (chains - 1) * gap;
+        SweepStep step{ilo, ihi, ws_, sw.nbc, adv, gap, sw.nbulges, spc, 0, 0, 0};
         hipStream_t const f = ws.far;
-        long issued = 0, last_waited_flush = -1;
-        int last_t = -2;
-        int const col_split = ihi;                      // columns >= ihi: deflated part, lazy
-        for (int t = 0; t < total_steps; t++) {
-            int cmin = (t - steps_per_chain + 1 + gap - 1) / gap;      // ceil for positives
-            if (t - steps_per_chain + 1 <= 0) cmin = 0;
+        int const col_split = sw.col_split;
+        for (; sw.t < total_steps; sw.t++) {
+            int const t = sw.t;
+            int cmin = (t - spc + 1 + gap - 1) / gap;      // ceil for positives
+            if (t - spc + 1 <= 0) cmin = 0;
             int const cmax = std::min(chains - 1, t / gap);
             if (cmax < cmin) continue;
+            // the leading chain is the first one still in flight
+            if (limit < ihi && ilo + (t - cmin * gap) * adv + ws_ + adv > limit) return false;
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
             // U buffers and events live in a ring indexed by a counter that runs across sweeps
@@ -566,7 +608,7 @@ struct Driver {
             if (ws.slot_flush[ev] >= 0) {
                 // the lazy streams must be through with the previous tenant of this U slot
                 long const fid = ws.slot_flush[ev];
-                if (fid != last_waited_flush) {
+                if (fid != sw.last_waited_flush) {
                     if (ws.flush_total - fid < SchurWorkspace::FLUSH_RING) {
                         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.h_done[(int)(fid % SchurWorkspace::FLUSH_RING)], 0));
                         if (Q) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.q_done[(int)(fid % SchurWorkspace::FLUSH_RING)], 0));
@@ -577,7 +619,7 @@ struct Driver {
                             SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
                         }
                     }
-                    last_waited_flush = fid;
+                    sw.last_waited_flush = fid;
                 }
                 ws.slot_flush[ev] = -1;
             }
@@ -585,28 +627,28 @@ struct Driver {
             // steps are skipped (a chain finishes before the next one is introduced) and the new
             // chain's first window would race with the finished chain's pending updates
             // (tests/test_schur_pipeline.py checks this rule on a model of the schedule).
-            if (issued > 0 && last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            if (sw.issued > 0 && sw.last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
                 step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
-            st.chase_launches++;
+            sweep_launches++;
             int min_lo = n, max_lo = 0;
             for (int k = 0; k < ntasks; k++) {
                 ChaseTask const tk = make_task(step, k);
                 int const rc = n - (tk.lo + tk.n);
                 min_lo = std::min(min_lo, tk.lo); max_lo = std::max(max_lo, tk.lo);
-                st.gemm_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
+                sweep_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
             }
             // rows above T0 are out of reach of every chain still in flight and of the AED windows
             // that follow this sweep (guard row)
             // (while chains are still being introduced at the top, every row is within reach)
             int const rear = (cmax == chains - 1) ? min_lo : ilo;
             int const row_split = std::max(0, std::min(rear, ws.guard_row));
-            if (issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            if (sw.issued > 0) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(schur_update_kernel<2>, dim3(1, ntasks), dim3(256),
                 UPDATE_LDS_BYTES_L, s, step, H, ldH, Q, ldQ, n, Ubuf, 0, n);
             SN_HIP_CHECK(hipEventRecord(ws.near_done[ev], s));
             SN_HIP_CHECK(hipStreamWaitEvent(f, ws.near_done[ev], 0));
-            // timely: columns [lo+w+adv, ihi) and rows [T0, lo).  Two launches: the left update of
+            // timely: columns [lo+w+adv, col_split) and rows [T0, lo).  Two launches: the left update of
             // one chain and the right update of a chain ahead of it meet in the same entries
             int const timely_cols = col_split - (min_lo + ws_ + adv), timely_rows = max_lo - row_split;
             if (timely_cols > 0)
@@ -616,18 +658,37 @@ struct Driver {
                 hipLaunchKernelGGL(schur_update_kernel<1>, dim3(divceil(timely_rows, 128), ntasks), dim3(256),
                     UPDATE_LDS_BYTES_R, f, step, H, ldH, Q, ldQ, n, Ubuf, row_split, n);
             SN_HIP_CHECK(hipEventRecord(ws.far_done[ev], f));
-            // the lazy parts of this step are issued when the sweep is through (see flush_lazy)
+            // the lazy parts of this step are issued later (flush_lazy)
             lazy.push_back(LazyItem{step, ev, row_split});
-            if ((int)lazy.size() >= SchurWorkspace::EV_RING / 2) flush_lazy(col_split);
-            issued++;
+            // Phase A of a look-ahead sweep is off the host's critical path and latency-bound on
+            // the GPU: its lazy updates are issued in small batches and fill the idle CUs, so that
+            // they are through when the AED chain ends.  Otherwise they wait for the sweep's end.
+            int const batch = (limit < ihi) ? lazy_batch : SchurWorkspace::EV_RING / 2;
+            if ((int)lazy.size() >= batch) flush_lazy(col_split);
+            sw.issued++;
             ws.issued_total++;
-            last_t = t;
+            sw.last_t = t;
         }
-        // the sweep is complete when the far stream has drained
-        if (issued > 0)
+        return true;
+    }
+
+    void sweep_finish()
+    {
+        sweep_issue(sw.ihi);
+        // the critical part of the sweep is complete when the far stream has drained
+        if (sw.issued > 0)
             SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % SchurWorkspace::EV_RING)], 0));
-        flush_lazy(col_split);
+        flush_lazy(sw.col_split);
+        sw.active = false;
         st.sweeps++;
+        st.gemm_flops += sweep_flops; st.chase_launches += sweep_launches;
+        sweep_flops = 0.0; sweep_launches = 0;
+    }
+
+    void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
+    {
+        sweep_begin(ilo, ihi, nshifts, sr, si);
+        sweep_finish();
     }
 };
 
@@ -697,22 +758,56 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
 
     std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
+    // Look-ahead: after a sweep the next one is started at once with the shifts at hand (stale
+    // by one AED chain -- measured: no effect on the number of sweeps) and runs down to the
+    // guard row while the host reduces the AED windows below it on a separate stream; when the
+    // chain of AEDs ends, the sweep continues through the rest of the block (phase B).
+    static bool const lookahead = getenv("SN_SCHUR_NOLOOKAHEAD") == nullptr;
+    std::vector<double> stale_r, stale_i;
+    d.ts = s;
+    auto replicate = [&](int nsh) {        // shift multiplicity (see `reuse` above)
+        for (int r = 1; r < reuse; r++)
+            for (int k = 0; k < nsh; k++) { sr[r * nsh + k] = sr[k]; si[r * nsh + k] = si[k]; }
+        return nsh * reuse;
+    };
+    auto finish_lookahead = [&](int ihi_now) {
+        // phase B: the AED stream is done with the bottom of the block, the lazy H updates issued
+        // so far (phase A, AED) are waited for -- rows near the guard row become timely again
+        SN_HIP_CHECK(hipEventRecord(ws.aed_mark, ws.aed));
+        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.aed_mark, 0));
+        d.ts = s;
+        // the next AED chain will work above ihi_now - 8 nw: make those rows timely now, while
+        // the lazy stream is waited for anyway
+        ws.guard_row = std::max(0, std::min(ws.guard_row, ihi_now - 8 * nw_conf));
+        d.wait_lazy_h();
+        d.sw.ihi = ihi_now; d.sw.col_split = ihi_now;
+        double const t_issue = wall();
+        d.sweep_finish();
+        d.prof_issue += wall() - t_issue;
+    };
     int rc = STARNEIG_SUCCESS;
     int ihi = n;                    // H(ihi:n, ihi:n) is already quasi-triangular
     int iter = 0, stagnation = 0;
     while (ihi > 0) {
         // ---- locate the active block [ilo, ihi) ------------------------------------------------
-        hipLaunchKernelGGL(schur_scan_subdiag_kernel, dim3(divceil(std::max(ihi - 1, 1), 256)), dim3(256),
-            0, s, 0, ihi, dH, ldH, thres, ws.dSub, n);
-        if (ihi > 1) {
+        bool const la = d.sw.active;        // the head of a sweep is in flight above the guard row
+        int const scan_lo = la ? ws.guard_row : 0;
+        if (la && ihi - scan_lo < 4) { finish_lookahead(ihi); continue; }
+        hipLaunchKernelGGL(schur_scan_subdiag_kernel, dim3(divceil(std::max(ihi - scan_lo - 1, 1), 256)), dim3(256),
+            0, d.ts, scan_lo, ihi, dH, ldH, thres, ws.dSub, n);
+        if (ihi - scan_lo > 1) {
             double tw = wall();
-            SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
-            SN_HIP_CHECK(hipStreamSynchronize(s));
+            SN_HIP_CHECK(hipMemcpyAsync(ws.hSub + scan_lo, ws.dSub + scan_lo, (size_t)(ihi - 1 - scan_lo) * 8,
+                hipMemcpyDeviceToHost, d.ts));
+            SN_HIP_CHECK(hipStreamSynchronize(d.ts));
             d.st.wait_s += wall() - tw; d.prof_scan_wait += wall() - tw;
         }
         int ilo = ihi - 1;
-        while (ilo > 0 && ws.hSub[ilo - 1] != 0.0) ilo--;
-        int const size = ihi - ilo;
+        while (ilo > scan_lo && ws.hSub[ilo - 1] != 0.0) ilo--;
+        // during look-ahead ilo == guard row means: no split found below the guard, the block
+        // continues upwards to the top of the sweep in flight
+        bool const open_top = la && ilo == scan_lo;
+        int const size = open_top ? ihi - d.sw.ilo : ihi - ilo;
         if (size == 1) {
             if (real) {
                 double v; SN_HIP_CHECK(hipMemcpy(&v, dH + (size_t)ilo * ldH + ilo, 8, hipMemcpyDeviceToHost));
@@ -728,14 +823,45 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         }
         if (iter >= iter_limit * std::max(1, n / std::max(1, ns_conf))) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
+        // ---- start the next sweep ahead of the AED chain -------------------------------------------
+        if (!la && lookahead && !stale_r.empty() && stagnation == 0) {
+            int const r1 = ihi - 8 * nw_conf;
+            if (r1 - ilo >= 4 * (WS_MAX + 64)) {
+                int nsh = (int)stale_r.size();
+                for (int k = 0; k < nsh; k++) { sr[k] = stale_r[k]; si[k] = stale_i[k]; }
+                nsh = replicate(nsh);
+                // (the guard row was already lowered to this value before phase B of the previous
+                // sweep, so that nothing lazy is pending below it and no wait is needed here)
+                d.set_guard_row(r1);
+                // the AED stream starts where the critical stream stands now: behind the previous
+                // sweep and behind the lazy updates of rows that a lowered guard row made timely
+                SN_HIP_CHECK(hipEventRecord(ws.aed_mark, s));
+                SN_HIP_CHECK(hipStreamWaitEvent(ws.aed, ws.aed_mark, 0));
+                double const t_issue = wall();
+                d.sweep_begin(ilo, ihi, nsh, sr.data(), si.data());
+                d.sw.col_split = r1;            // phase A: the columns of the AED region are lazy
+                d.sweep_issue(r1);
+                d.flush_lazy(r1);               // ... run while the host is busy with the AEDs
+                d.prof_issue += wall() - t_issue;
+                d.ts = ws.aed;
+                iter++;
+            }
+        }
+        bool const la_now = d.sw.active;
+
         // ---- aggressive early deflation on the trailing window ---------------------------------
         int nw = std::min(nw_conf, size);
         if (stagnation > 0) nw = std::min(size, std::min(wmax, nw + nw / 20 * stagnation + 2));  // core.c:1912-1918
+        if (la_now && ihi - nw <= ws.guard_row + 1) {
+            // the AED chain has reached the guard row: let the sweep through first
+            finish_lookahead(ihi);
+            continue;
+        }
         int const kw = ihi - nw;
         double sub = 0.0;
-        if (kw > ilo) sub = ws.hSub[kw - 1];
+        if (kw > ilo || (open_top && kw > d.sw.ilo)) sub = ws.hSub[kw - 1];
         int const ldh = Driver::host_ld(nw);
-        if (kw < ws.guard_row) d.set_guard_row(kw - 4 * nw);
+        if (!la_now && kw < ws.guard_row) d.set_guard_row(kw - 4 * nw);
         d.download_window(kw, nw, ws.hWin, ldh);
         double t_aed0 = wall();
         host::AedResult ar = host::aed_window(nw, ws.hWin, ldh, ws.hZ, ldh, sub, thres,
@@ -745,11 +871,11 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         if (ar.deflated > 0) {
             d.upload_window(kw, nw, ws.hWin, ldh);
             d.upload_matrix(ws.dZ, ws.hZ, ldh, nw);
-            if (kw > ilo)
-                hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, s,
+            if (sub != 0.0)
+                hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, d.ts,
                     dH + (size_t)(kw - 1) * ldH + kw, spike[0]);
             d.apply_transform(kw, nw, ws.dZ, nw);
-            SN_HIP_CHECK(hipStreamSynchronize(s));
+            SN_HIP_CHECK(hipStreamSynchronize(d.ts));
             if (real) {
                 std::vector<double> wr(nw), wi(nw);
                 host::extract_eigenvalues(ar.deflated, ws.hWin + (size_t)(nw - ar.deflated) * ldh + (nw - ar.deflated),
@@ -761,15 +887,16 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             ihi -= ar.deflated;
             stagnation = 0;
         } else stagnation++;
-        if (ihi - ilo <= small_limit) continue;
+        int const size_now = open_top ? ihi - d.sw.ilo : ihi - ilo;
+        if (size_now <= small_limit && !la_now) continue;
         // enough deflation: try AED again before spending a sweep (nibble rule, process_args.c:356)
-        if (100 * ar.deflated > nibble * nw) continue;
+        if (100 * ar.deflated > nibble * nw && size_now > small_limit) continue;
         int nshifts = std::min(ar.shifts, ns_conf);
         nshifts -= nshifts % 2;
         // Exceptional shifts (the LAPACK dlaqr0 recipe, every 6th sweep without deflation, or
         // when the window offers no usable shift -- e.g. a nilpotent trailing block): pairs
         // from [0.75 s + h_ii, s; -0.4375 s, 0.75 s + h_ii], s = |h_{i,i-1}| + |h_{i-1,i-2}|.
-        if (nshifts < 2 || (stagnation > 0 && stagnation % 6 == 0)) {
+        if (!la_now && (nshifts < 2 || (stagnation > 0 && stagnation % 6 == 0))) {
             int const want = std::max(2, std::min(ns_conf, (ihi - ilo - 2) / 2 * 2));
             std::vector<double> dg(want + 2);
             int const first = ihi - (want + 2) >= 0 ? ihi - (want + 2) : 0;
@@ -788,23 +915,13 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             if (nshifts < 2) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
         }
         if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+        // the shifts of this AED serve the sweep that is started after the one in flight
+        if (nshifts >= 2) { stale_r.assign(sr.begin(), sr.begin() + nshifts); stale_i.assign(si.begin(), si.begin() + nshifts); }
 
         // ---- multi-shift sweep -----------------------------------------------------------------------
-        {
-            static bool const stale = getenv("SN_SCHUR_STALE") != nullptr;     // experiment
-            static std::vector<double> psr, psi; static int pn = 0;
-            if (stale) {
-                std::vector<double> csr(sr.begin(), sr.begin() + nshifts), csi(si.begin(), si.begin() + nshifts);
-                int cn = nshifts;
-                if (pn >= 2) { nshifts = pn; for (int k = 0; k < pn; k++) { sr[k] = psr[k]; si[k] = psi[k]; } }
-                psr = csr; psi = csi; pn = cn;
-            }
-        }
-        if (reuse > 1 && ihi - ilo > 4 * WS_MAX) {
-            for (int r = 1; r < reuse; r++)
-                for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
-            nshifts *= reuse;
-        }
+        if (la_now) { finish_lookahead(ihi); continue; }
+        if (nshifts < 2) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
+        if (reuse > 1 && ihi - ilo > 4 * WS_MAX) nshifts = replicate(nshifts);
         // rows below the guard row stay timely: room for the AED windows that follow the sweep
         d.set_guard_row(ihi - 8 * nw_conf);
         double const t_issue = wall();
@@ -812,6 +929,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         d.prof_issue += wall() - t_issue;
         iter++;
     }
+    if (d.sw.active) finish_lookahead(ihi);     // (error exits: no bulges are left behind)
     // the lazy streams have to drain before the result is complete
     SN_HIP_CHECK(hipEventRecord(ws.lazy_mark, ws.hs));
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.lazy_mark, 0));
