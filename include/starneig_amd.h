@@ -57,6 +57,15 @@ starneig_error_t starneig_amd_schur_device(
     int n, double *dH, int ldH, double *dQ, int ldQ, double *real, double *imag,
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
+/* Row-sharded accumulation of Q: every GPU of a node reduces its own replica of
+ * H (the reduction is deterministic, the replicas stay bit-identical) but updates only the q_rows
+ * rows of Q that start at dQrows (= dQ + first_row, same leading dimension) -- 45 % of the update
+ * flops of the Schur leg shard this way without any communication; the caller assembles Q
+ * afterwards (starneig_amd/distributed.py: zero the rows a rank does not own, all-reduce). */
+starneig_error_t starneig_amd_schur_rows_device(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats);
+
 /* Generalized twin (BASELINE config 5): the device-resident Hessenberg-triangular pencil
  * (dH, dR) <- generalized real Schur form, dQ <- dQ*U1, dZ <- dZ*U2 (either may be NULL).
  * real/imag/beta are HOST arrays of length n (all NULL = not extracted).  Same conf and

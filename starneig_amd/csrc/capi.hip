@@ -429,6 +429,33 @@ SN_API starneig_error_t starneig_amd_schur_device(
     return rc;
 }
 
+SN_API starneig_error_t starneig_amd_schur_rows_device(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (dH == NULL)            return -2;
+    if (ldH < n)               return -3;
+    if (dQrows == NULL)        return -4;
+    if (ldQ < q_rows)          return -5;
+    if (q_rows < 0 || q_rows > n) return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    sn::SchurParams prm;
+    int rc = schur_params_from_conf(conf, prm);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    sn::SchurStats st;
+    hipStream_t s = (hipStream_t)stream;
+    if (real == NULL || imag == NULL) real = imag = nullptr;
+    rc = sn::schur_device(s, n, dH, ldH, dQrows, ldQ, real, imag, prm, &st, q_rows);
+    SN_HIP_CHECK(hipStreamSynchronize(s));
+    if (stats) {
+        stats[0] = st.total_ms; stats[1] = st.sweeps; stats[2] = st.aeds;
+        stats[3] = st.small_solves; stats[4] = st.chase_launches; stats[5] = st.gemm_flops;
+        stats[6] = st.aed_host_s; stats[7] = st.wait_s;
+    }
+    return rc;
+}
+
 SN_API starneig_error_t starneig_amd_hessenberg_device(
     int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, void *stream, double *stats)

@@ -100,8 +100,10 @@ struct SchurStats {
 };
 // Reduces the device-resident upper Hessenberg matrix dH to real Schur form, dQ <- dQ*U.
 // real/imag are HOST arrays (may be NULL).  Returns a starneig_error_t value.
+// q_rows >= 0: dQ points at a block of q_rows rows of Q and only those are updated (row-sharded
+// accumulation of Q over several GPUs that each reduce a replica of H).
 int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
-    double *real, double *imag, SchurParams const &params, SchurStats *stats);
+    double *real, double *imag, SchurParams const &params, SchurStats *stats, int q_rows = -1);
 void schur_release_workspace();
 // Generalized twin (schur_gep.hip): (dA, dB) Hessenberg-triangular -> generalized Schur form
 int gep_schur_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,

@@ -378,6 +378,9 @@ struct Driver {
     // stream of the window downloads/uploads and of the timely AED / small-block updates: the
     // critical stream, or the AED stream while the head of the next sweep is in flight on s
     hipStream_t ts = nullptr;
+    // rows of Q this process updates (Q points at the first of them): all n, or the row block of
+    // a rank when several GPUs reduce replicas of H and share the accumulation of Q
+    int nq = 0;
 
     // the critical stream waits until the lazy H updates issued so far are done
     void wait_lazy_h()
@@ -442,10 +445,10 @@ struct Driver {
         right_update(ws.hs, H, ldH, 0, split, lo, w, Zc, w, ws.dTmpH);
         SN_HIP_CHECK(hipEventRecord(ws.zh_done[slot], ws.hs));
         SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.z_ready[slot], 0));
-        if (Q) right_update(ws.qs, Q, ldQ, 0, n, lo, w, Zc, w, ws.dTmpQ);
+        if (Q) right_update(ws.qs, Q, ldQ, 0, nq, lo, w, Zc, w, ws.dTmpQ);
         SN_HIP_CHECK(hipEventRecord(ws.z_done[slot], ws.qs));
         ws.z_total++;
-        st.gemm_flops += 2.0 * w * w * ((double)right_cols + lo + (Q ? n : 0));
+        st.gemm_flops += 2.0 * w * w * ((double)right_cols + lo + (Q ? nq : 0));
     }
 
     void download_window(int lo, int w, double *h, int ldh)
@@ -514,8 +517,8 @@ struct Driver {
                     dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
                     UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
             if (Q)
-                hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(n, 128), ntasks),
-                    dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, n, Ubuf, 0, n);
+                hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(nq, 128), ntasks),
+                    dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, nq, Ubuf, 0, nq);
             ws.slot_flush[it.ev] = ws.flush_total;
         }
         SN_HIP_CHECK(hipEventRecord(ws.h_done[fslot], ws.hs));
@@ -636,7 +639,7 @@ struct Driver {
                 ChaseTask const tk = make_task(step, k);
                 int const rc = n - (tk.lo + tk.n);
                 min_lo = std::min(min_lo, tk.lo); max_lo = std::max(max_lo, tk.lo);
-                sweep_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? n : 0));
+                sweep_flops += 2.0 * tk.n * tk.n * ((double)rc + tk.lo + (Q ? nq : 0));
             }
             // rows above T0 are out of reach of every chain still in flight and of the AED windows
             // that follow this sweep (guard row)
@@ -695,7 +698,7 @@ struct Driver {
 } // namespace
 
 int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int ldQ,
-    double *real, double *imag, SchurParams const &prm, SchurStats *stats)
+    double *real, double *imag, SchurParams const &prm, SchurStats *stats, int q_rows)
 {
     // the whole reduction runs on the library's own stream pair (never on the legacy NULL
     // stream), fenced against the caller's stream at entry and exit
@@ -765,6 +768,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     static bool const lookahead = getenv("SN_SCHUR_NOLOOKAHEAD") == nullptr;
     std::vector<double> stale_r, stale_i;
     d.ts = s;
+    d.nq = (q_rows >= 0) ? q_rows : n;
     auto replicate = [&](int nsh) {        // shift multiplicity (see `reuse` above)
         for (int r = 1; r < reuse; r++)
             for (int k = 0; k < nsh; k++) { sr[r * nsh + k] = sr[k]; si[r * nsh + k] = si[k]; }

@@ -81,6 +81,8 @@ SIGNATURES = {
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _dp, _vp]),
     "starneig_amd_schur_device": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
+    "starneig_amd_schur_rows_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
         C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
     "starneig_amd_hessenberg_panel_ld": (C.c_int, [C.c_int, C.c_int]),

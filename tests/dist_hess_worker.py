@@ -44,6 +44,26 @@ def main():
         print(f"DIST-OK world={world} n={n} pw={pw} residual={c['residual_u']:.1f}u "
               f"diff={diff / 2.0**-52:.1f}u collectives={st['collectives']}", flush=True)
     dist.barrier()
+    # ---- Schur leg: replicas of H, row-sharded accumulation of Q ---------------------------------
+    tH0, tQ0 = tA.clone(), tQ.clone()
+    rc, real, imag, sst = D.schur_sharded(tA, tQ, n=n)
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    chk = torch.stack([tA.abs().sum(), tQ.abs().sum()]).cpu()
+    ref = chk.clone(); dist.broadcast(ref, src=0)
+    assert torch.equal(chk, ref), (rank, chk, ref)          # replicas are bit-identical
+    if rank == 0:
+        rc, c = S.check_device(tQ, tA, tA0, n=n)
+        assert rc == 0 and c["below_subdiagonal"] == 0, c
+        assert c["residual_u"] < 500 and c["orthogonality_u"] < 500, c
+        # equals the single-GPU Schur reduction of the same Hessenberg matrix bit for bit
+        rc, real1, imag1, _ = S.schur_device(tH0, tQ0, n=n)
+        assert rc == 0
+        assert torch.equal(tH0, tA) and torch.equal(tQ0[:, :n], tQ[:, :n])
+        assert np.array_equal(real, real1) and np.array_equal(imag, imag1)
+        print(f"DIST-SCHUR-OK world={world} n={n} residual={c['residual_u']:.1f}u rows={sst['q_rows']}",
+              flush=True)
+    dist.barrier()
     S.node_finalize()
     dist.destroy_process_group()
 

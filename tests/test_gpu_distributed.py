@@ -1,4 +1,5 @@
-"""GPU: the N > 1 (sharded) Hessenberg path with 2 and 3 processes sharing cuda:0 over gloo."""
+"""GPU: the N > 1 paths (block-column sharded Hessenberg, row-sharded accumulation of Q in the
+Schur leg) with 2 and 3 processes sharing cuda:0 over gloo."""
 import os
 import subprocess
 import sys
@@ -9,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n,pw", [(2, 700, 64), (3, 1000, 96), (2, 333, 40)])
+@pytest.mark.parametrize("world,n,pw", [(2, 700, 64), (3, 1000, 96), (2, 333, 40), (2, 2600, 128)])
 def test_sharded_hessenberg_matches_single_gpu(world, n, pw):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -18,3 +19,4 @@ def test_sharded_hessenberg_matches_single_gpu(world, n, pw):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DIST-SCHUR-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
