@@ -269,7 +269,8 @@ struct SchurWorkspace {
     hipStream_t far = nullptr, qs = nullptr, hs = nullptr;    // timely far H updates; lazy Q; lazy H
     hipStream_t aed = nullptr;      // window traffic and timely AED updates while a sweep head is in flight
     hipEvent_t aed_mark = nullptr;
-    static constexpr int EV_RING = 2048;        // = ring of per-step U buffers (the lazy streams lag a sweep)
+    static constexpr int EV_RING = 2048;        // largest ring of per-step U buffers (the lazy streams lag a sweep)
+    int ring = EV_RING;                         // ring in use: ~4 sweeps' worth of window steps
     hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
     static constexpr int FLUSH_RING = 16;       // lazy launches are issued in batches; one event pair per batch
     hipEvent_t q_done[FLUSH_RING] = {}, h_done[FLUSH_RING] = {};
@@ -295,7 +296,9 @@ struct SchurWorkspace {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
-        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)EV_RING * max_chains * WS_MAX * WS_MAX * 8));
+        ring = std::min(EV_RING, std::max(64, 4 * (n / 40 + 128)));
+        std::fill(slot_flush.begin(), slot_flush.end(), -1L);
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)ring * max_chains * WS_MAX * WS_MAX * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dZq, (size_t)Z_RING * nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmpH, (size_t)n * nwmax * 8));
@@ -605,8 +608,8 @@ struct Driver {
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
             // U buffers and events live in a ring indexed by a counter that runs across sweeps
-            int const ev = (int)(ws.issued_total % SchurWorkspace::EV_RING);
-            int const evp = (int)((ws.issued_total + SchurWorkspace::EV_RING - 1) % SchurWorkspace::EV_RING);
+            int const ev = (int)(ws.issued_total % ws.ring);
+            int const evp = (int)((ws.issued_total + ws.ring - 1) % ws.ring);
             double *Ubuf = ws.dU + (size_t)ev * ws.max_chains * WS_MAX * WS_MAX;
             if (ws.slot_flush[ev] >= 0) {
                 // the lazy streams must be through with the previous tenant of this U slot
@@ -666,7 +669,7 @@ struct Driver {
             // Phase A of a look-ahead sweep is off the host's critical path and latency-bound on
             // the GPU: its lazy updates are issued in small batches and fill the idle CUs, so that
             // they are through when the AED chain ends.  Otherwise they wait for the sweep's end.
-            int const batch = (limit < ihi) ? lazy_batch : SchurWorkspace::EV_RING / 2;
+            int const batch = (limit < ihi) ? lazy_batch : ws.ring / 2;
             if ((int)lazy.size() >= batch) flush_lazy(col_split);
             sw.issued++;
             ws.issued_total++;
@@ -680,7 +683,7 @@ struct Driver {
         sweep_issue(sw.ihi);
         // the critical part of the sweep is complete when the far stream has drained
         if (sw.issued > 0)
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % SchurWorkspace::EV_RING)], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % ws.ring)], 0));
         flush_lazy(sw.col_split);
         sw.active = false;
         st.sweeps++;

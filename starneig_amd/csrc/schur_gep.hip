@@ -269,7 +269,8 @@ struct GepWorkspace {
     double *hA = nullptr, *hB = nullptr, *hQ = nullptr, *hZ = nullptr, *hSub = nullptr;   // pinned
     bool attr_set = false;
     hipStream_t far = nullptr, qs = nullptr;    // far updates of A, B; lazy updates of Q, Z
-    static constexpr int EV_RING = 2048;        // ring of per-step factor buffers
+    static constexpr int EV_RING = 2048;        // largest ring of per-step factor buffers
+    int ring = EV_RING;                         // ring in use
     hipEvent_t near_done[EV_RING] = {}, far_done[EV_RING] = {};
     static constexpr int FLUSH_RING = 16;
     hipEvent_t q_done[FLUSH_RING] = {};
@@ -294,7 +295,9 @@ struct GepWorkspace {
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
         size_t const w2 = (size_t)(nwmax + 8) * nwmax * 8;
-        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)EV_RING * max_chains * 2 * GWS * GWS * 8));
+        ring = std::min(EV_RING, std::max(64, 4 * (n / 30 + 128)));
+        std::fill(slot_flush.begin(), slot_flush.end(), -1L);
+        SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)ring * max_chains * 2 * GWS * GWS * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dQZq, (size_t)Z_RING * 2 * nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
@@ -501,8 +504,8 @@ struct GepDriver {
             step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
             int const ntasks = step.ntasks;
             // factor buffers and events live in a ring that runs across sweeps (schur.hip)
-            int const ev = (int)(ws.issued_total % GepWorkspace::EV_RING);
-            int const evp = (int)((ws.issued_total + GepWorkspace::EV_RING - 1) % GepWorkspace::EV_RING);
+            int const ev = (int)(ws.issued_total % ws.ring);
+            int const evp = (int)((ws.issued_total + ws.ring - 1) % ws.ring);
             double *Ubuf = ws.dU + (size_t)ev * ws.max_chains * 2 * GWS * GWS;
             if (ws.slot_flush[ev] >= 0) {
                 long const fid = ws.slot_flush[ev];
@@ -547,10 +550,10 @@ struct GepDriver {
             issued++;
             ws.issued_total++;
             last_t = t;
-            if ((int)lazy.size() >= GepWorkspace::EV_RING / 2) flush_lazy();
+            if ((int)lazy.size() >= ws.ring / 2) flush_lazy();
         }
         if (issued > 0)
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % GepWorkspace::EV_RING)], 0));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[(int)((ws.issued_total - 1) % ws.ring)], 0));
         flush_lazy();
         st.sweeps++;
     }
