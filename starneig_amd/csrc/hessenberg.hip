@@ -55,7 +55,10 @@ __device__ __forceinline__ double wave_sum(double x)
 }
 
 constexpr int RB = 64;           // rows per workgroup in the row-parallel column kernels
-constexpr int NG = 4;            // column groups (= waves) sharing one row in those kernels
+constexpr int NG = 4;            // column groups (= waves) sharing one row in colA / finish
+constexpr int CT = 64 * NG;      // threads of colA / finish
+constexpr int NGC = 16;          // colC: its column loop is latency-bound, 16 groups cut it from 15 to 10 us
+constexpr int CTC = 64 * NGC;    // (colA gets slower with 16: 23 -> 36 us)
 constexpr int RBS = 16, NGS = 16; // rows / column groups of a shadow block inside the gemv launch
 constexpr int GEMV_ROWS = 512;   // rows per workgroup of the big gemv (4 waves x 64 lanes x 2)
 constexpr int MAX_SPLIT = 32;
@@ -95,8 +98,9 @@ __device__ __forceinline__ double nrm_sum(double const *__restrict__ acc, int pa
 }
 
 // In-block transposed gemv: out[l] += sum_{r<RB} M[g0+r, l] * sp[r], l < ncols.
-// 256 threads = 16 row lanes x 16 column groups; 16 lanes read 128 contiguous
+// CT threads = 16 row lanes x CT/16 column groups; 16 lanes read 128 contiguous
 // bytes of one column, the 16-lane DPP row reduces them, one atomic per column.
+template <int THREADS>
 __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M, int ldm,
     int g0, int ncols, double const *sp, double *__restrict__ out)
 {
@@ -104,7 +108,7 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
     double pr[RB / 16];
     #pragma unroll
     for (int it = 0; it < RB / 16; it++) pr[it] = sp[it * 16 + rsub];
-    for (int l = csub; l < ncols; l += 16) {
+    for (int l = csub; l < ncols; l += THREADS / 16) {
         double const *col = M + (size_t)l * ldm + g0 + rsub;
         double acc = 0.0;
         #pragma unroll
@@ -115,7 +119,7 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
 }
 
 // colA(j), j >= 1.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(CT)
 void hess_colA_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double const *__restrict__ VT,
     double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
@@ -133,7 +137,7 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     __syncthreads();
     {
         double const scale = s_scal[0];
-        for (int l = tid; l < j; l += 256) {
+        for (int l = tid; l < j; l += CT) {
             double vr = V[(size_t)l * ldp + pivprev];          // V(piv-1, l); = 1 for l = j-1
             s_vrow[l] = vr;
             s_wv[l] = (l < j - 1)
@@ -180,12 +184,12 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     }
     __syncthreads();
     // w += VT(rows,0:j)^T p'   (rows past E contribute 0 through s_p)
-    block_gemv_t_atomic(VT, ldp, g0, j, s_p,
+    block_gemv_t_atomic<CT>(VT, ldp, g0, j, s_p,
         acc + ACC_WSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
 }
 
 // After the last column of a panel: finish Y(:,nb-1) and finalize P(:,nb-1).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(CT)
 void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double *__restrict__ Y,
     double const *__restrict__ ypart, int nsplit, double const *__restrict__ acc,
@@ -198,7 +202,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     int const pivprev = R0 + j - 1, parp = (j - 1) & 1;
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
     __syncthreads();
-    for (int l = tid; l < j - 1; l += 256)
+    for (int l = tid; l < j - 1; l += CT)
         s_wv[l] = V[(size_t)l * ldp + pivprev]
             + s_scal[0] * slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l);
     __syncthreads();
@@ -220,30 +224,30 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
 }
 
 // colC(j): p'' = p' - V(:,0:j) w ; norm^2 below the pivot ; V^T p''(piv+1:)
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(CTC)
 void hess_colC_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc)
 {
-    __shared__ double s_w[MAXJ], s_p[RB], s_t[NG - 1][RB];
+    __shared__ double s_w[MAXJ], s_p[RB], s_t[NGC - 1][RB];
     int const tid = threadIdx.x;
     int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
     int const piv = R0 + j, par = j & 1;
-    for (int l = tid; l < j; l += 256)
+    for (int l = tid; l < j; l += CTC)
         s_w[l] = slot_sum(acc + ACC_WSUM + par * NSLOT * MAXJ, l);
     if (blockIdx.x == 0)      // wsum of the other parity: read by colC(j-1), re-used by colA(j+1)
-        for (int l = tid; l < NSLOT * MAXJ; l += 256)
+        for (int l = tid; l < NSLOT * MAXJ; l += CTC)
             acc[ACC_WSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
     __syncthreads();
     double a = 0.0;
     if (g < E) {
         double const *vrow = V + g;
         int l = h;
-        for (; l + 3 * NG < j; l += 4 * NG)
-            a += vrow[(size_t)(l + 0 * NG) * ldp] * s_w[l] + vrow[(size_t)(l + 1 * NG) * ldp] * s_w[l + NG]
-               + vrow[(size_t)(l + 2 * NG) * ldp] * s_w[l + 2 * NG] + vrow[(size_t)(l + 3 * NG) * ldp] * s_w[l + 3 * NG];
-        for (; l < j; l += NG) a += vrow[(size_t)l * ldp] * s_w[l];
+        for (; l + 3 * NGC < j; l += 4 * NGC)
+            a += vrow[(size_t)(l + 0 * NGC) * ldp] * s_w[l] + vrow[(size_t)(l + 1 * NGC) * ldp] * s_w[l + NGC]
+               + vrow[(size_t)(l + 2 * NGC) * ldp] * s_w[l + 2 * NGC] + vrow[(size_t)(l + 3 * NGC) * ldp] * s_w[l + 3 * NGC];
+        for (; l < j; l += NGC) a += vrow[(size_t)l * ldp] * s_w[l];
     }
     if (h > 0) s_t[h - 1][r] = a;
     __syncthreads();
@@ -253,7 +257,7 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
             double pval = P[(size_t)j * ldp + g];
             if (j > 0) {                                                    // cpu.c:123-130
                 #pragma unroll
-                for (int q = 0; q < NG - 1; q++) a += s_t[q][r];
+                for (int q = 0; q < NGC - 1; q++) a += s_t[q][r];
                 pval -= a;
                 P[(size_t)j * ldp + g] = pval;
             }
@@ -265,7 +269,7 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
             atomicAdd(acc + ACC_NRM + par * NSLOT + (blockIdx.x & (NSLOT - 1)), ss);
     }
     __syncthreads();
-    block_gemv_t_atomic(V, ldp, g0, j, s_p,
+    block_gemv_t_atomic<CTC>(V, ldp, g0, j, s_p,
         acc + ACC_WVSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
 }
 
@@ -519,9 +523,9 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         for (int j = 0; j < nb; j++) {
             int const piv = R0 + j;
             if (j > 0)
-                hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(256), 0, s,
+                hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
                     R0, E, j, ldp, ws.P, V, VT, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
-            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(256), 0, s,
+            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, ws.P, V, ws.acc);
             int const ncols = E - piv;
             choose_split(m, ncols, &nsplit, &cps);
@@ -552,7 +556,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             gemv_launches++;
             gemv_bytes += 8.0 * (double)m * (double)ncols;
         }
-        hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(256), 0, s,
+        hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
             R0, E, nb, ldp, ws.P, V, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
 
         // ---- critical trailing updates (core.c:523-547); VT = V*T comes from the panel ----
@@ -691,9 +695,9 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
         for (int j = 0; j < nb; j++) {
             int const piv = R0 + j;
             if (j > 0)
-                hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(256), 0, s,
+                hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
                     R0, E, j, ldp, dP, V, VT, ws.Y, dYsum, 1, ws.acc, ws.scal);
-            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(256), 0, s,
+            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, dP, V, ws.acc);
             int const b0 = piv / cb;
             int const first = b0 + ((rank - b0 % world) + world) % world;
@@ -719,7 +723,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             gemv_launches++;
             gemv_bytes += 8.0 * (double)m * (double)(E - piv) / world;
         }
-        hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(256), 0, s,
+        hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
             R0, E, nb, ldp, dP, V, ws.Y, dYsum, 1, ws.acc, ws.scal);
 
         // trailing updates on the owned blocks right of the panel (core.c:523-547)
