@@ -6,13 +6,20 @@
 // sweeps, AED with the norm-stable deflation criterion |sub*Z(0,i)| < u*||H||_F, shifts
 // ordered/paired as starneig_extract_shifts does, 40 % nibble rule, 2x2 blocks in dlanv2
 // standard form, eigenvalues extracted from the diagonal blocks).  What is re-designed for
-// the GPU: H and Q never leave HBM; there is ONE level of diagonal windows (<= 96 rows, held
-// in LDS together with the accumulated orthogonal factor) instead of the reference's
-// 2*tile-row windows with 50x50 sub-windows; all chains of a sweep advance together in one
-// launch (one workgroup per chain) and every off-diagonal update is an in-place fp64-MFMA
-// GEMM.  The sequential small dense problems (AED window, final small blocks) run on the
-// host on copies of the window (schur_host.hip), like the reference's CPU-only window tasks
-// (schur/tasks.c:203-261 have no .cuda_funcs).
+// the GPU:
+//  - H and Q never leave HBM; ONE level of diagonal windows (<= 96 rows, held in LDS together
+//    with the accumulated orthogonal factor) instead of the reference's 2*tile-row windows with
+//    50x50 sub-windows; all chains of a sweep advance together in one launch per window step
+//    (one workgroup per chain); every off-diagonal update is an in-place fp64-MFMA GEMM;
+//  - every shift pair drives several bulges (shift multiplicity), the sweeps are few and wide;
+//  - updates are split into a timely zone (what later window steps and AED windows read: far
+//    stream, one step behind the chase) and lazy zones (Q, the deflated columns, rows above the
+//    chain band: low-priority streams, executed while the host is busy);
+//  - look-ahead: the head of the next sweep runs above a guard row while the host reduces the
+//    chain of AED windows below it on a separate stream;
+//  - the sequential small dense problems (AED window, final small blocks) run on the host on
+//    copies of the window (schur_host.hip), like the reference's CPU-only window tasks
+//    (schur/tasks.c:203-261 have no .cuda_funcs).
 #include "common.h"
 #include "schur_host.h"
 #include "dgemm_tile.h"
@@ -256,15 +263,12 @@ __global__ void schur_set_entry_kernel(double *p, double v) { *p = v; }
 struct SchurWorkspace {
     int n = 0, nwmax = 0, max_chains = 0;
     double *dU = nullptr;           // max_chains x WS_MAX x WS_MAX
-    ChaseTask *dTasks = nullptr;
-    GemmDesc *dDescs = nullptr, *hDescs = nullptr;
     double *dShiftR = nullptr, *dShiftI = nullptr;
     double *dSub = nullptr;         // n
     double *dWin = nullptr, *dZ = nullptr, *dTmp = nullptr;   // nwmax^2, nwmax^2, n*nwmax
     double *dAcc = nullptr;
     double *hWin = nullptr, *hZ = nullptr, *hSub = nullptr, *hShift = nullptr;   // pinned
     long shift_uploads = 0;
-    ChaseTask *hTasks = nullptr;
     bool attr_set = false;
     hipStream_t far = nullptr, qs = nullptr, hs = nullptr;    // timely far H updates; lazy Q; lazy H
     hipStream_t aed = nullptr;      // window traffic and timely AED updates while a sweep head is in flight
@@ -285,10 +289,10 @@ struct SchurWorkspace {
     hipEvent_t lazy_mark = nullptr;
 
     void release() {
-        void **dptrs[] = {(void **)&dU, (void **)&dTasks, (void **)&dDescs, (void **)&dShiftR, (void **)&dShiftI,
+        void **dptrs[] = {(void **)&dU, (void **)&dShiftR, (void **)&dShiftI,
             (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc, (void **)&dZq, (void **)&dTmpQ, (void **)&dTmpH};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
-        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hShift, (void **)&hTasks, (void **)&hDescs};
+        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hShift};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
         n = nwmax = max_chains = 0;
     }
@@ -500,7 +504,7 @@ struct Driver {
     // from the timely to the lazy zone within a sweep) and Q.  They are issued after the
     // critical path of the sweep so that they execute while the host reduces the AED windows
     // that follow, instead of competing with the sweep for the CUs.
-    double prof_scan_wait = 0, prof_dl_wait = 0, prof_issue = 0, prof_guard = 0; int prof_guard_moves = 0;
+    double prof_scan_wait = 0, prof_dl_wait = 0, prof_issue = 0; int prof_guard_moves = 0;
     struct LazyItem { SweepStep step; int ev; int row_split; };
     std::vector<LazyItem> lazy;
     void flush_lazy(int col_split)
