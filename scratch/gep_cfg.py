@@ -7,11 +7,13 @@ n = int(sys.argv[1])
 tH0, tR0 = S.device_matrix(n), S.device_matrix(n)
 S.lcg_pencil_device(tH0, tR0, n)
 for cfg in sys.argv[2:]:
-    aed, ns, small = [int(x) for x in cfg.split(",")]
+    parts = [int(x) for x in cfg.split(",")]
+    aed, ns, small = parts[:3]
+    nib = parts[3] if len(parts) > 3 else -1
     tH, tR = tH0.clone(), tR0.clone()
     tQ, tZ = S.device_matrix(n), S.device_matrix(n)
     S.set_matrix_device(tQ, n, n, 0.0, 1.0); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
-    conf = S.schur_init_conf(); conf.aed_window_size = aed; conf.shift_count = ns; conf.small_limit = small
+    conf = S.schur_init_conf(); conf.aed_window_size = aed; conf.shift_count = ns; conf.small_limit = small; conf.aed_nibble = nib
     torch.cuda.synchronize(); t = time.time()
     rc, ar, ai, be, st = S.gep_schur_device(tH, tR, tQ, tZ, n=n, conf=conf)
     torch.cuda.synchronize(); dt = time.time() - t
