@@ -290,6 +290,17 @@ def test_zone_schedule_is_race_free_and_ordered(n, nw, lookahead):
         assert tiles_exactly(region, pieces), (kind, region, pieces)
 
 
+@pytest.mark.parametrize("deflate,chain,chains,gw", [(10, 6, 2, 3), (60, 1, 4, 2), (25, 4, 3, 4), (40, 8, 2, 3)])
+def test_zone_schedule_variants(deflate, chain, chains, gw):
+    """long and short AED chains (a long one runs into the guard row), strong and weak deflation,
+    different guard distances and chain counts"""
+    for lookahead in (False, True):
+        d = Driver(1000, 64, guard_windows=gw).run(lookahead, deflate=deflate, chain=chain, chains=chains)
+        check(d.sch)
+        for kind, region, pieces in d.coverage:
+            assert tiles_exactly(region, pieces), (kind, region, pieces)
+
+
 def test_the_checker_sees_a_missing_wait():
     """without the wait for the lazy stream at the start of a sweep, rows that were above the band
     in the previous sweep race with the new sweep's timely updates"""
