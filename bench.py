@@ -148,8 +148,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        # SN_BENCH_BACKEND=gloo with SN_BENCH_ONE_GPU=1 runs the N > 1 code path with all ranks on
+        # cuda:0 (testing on a single-GPU box); the real runs use RCCL, one GPU per rank
+        backend = os.environ.get("SN_BENCH_BACKEND", "nccl")
+        if os.environ.get("SN_BENCH_ONE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     torch.zeros(1, device="cuda")
