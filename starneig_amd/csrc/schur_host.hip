@@ -97,9 +97,10 @@ static void rot_rows(double *T, int ldt, int r1, int r2, int c0, int c1, double 
 }
 static void rot_cols(double *T, int ldt, int c1, int c2, int r0, int r1, double cs, double sn)
 {
+    double *__restrict__ a = &T_(0, c1), *__restrict__ b = &T_(0, c2);      // distinct columns: vectorises
     for (int i = r0; i < r1; i++) {
-        double x = T_(i, c1), y = T_(i, c2);
-        T_(i, c1) = cs * x + sn * y; T_(i, c2) = cs * y - sn * x;
+        double x = a[i], y = b[i];
+        a[i] = cs * x + sn * y; b[i] = cs * y - sn * x;
     }
 }
 
@@ -195,26 +196,32 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                         T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2; T_(k2 + 2, j) -= sum * t3;
                     }
                     int je = std::min(k2 + 3, i);
-                    for (int j = 0; j <= je; j++) {
-                        double sum = T_(j, k2) + v2 * T_(j, k2 + 1) + v3 * T_(j, k2 + 2);
-                        T_(j, k2) -= sum * t1; T_(j, k2 + 1) -= sum * t2; T_(j, k2 + 2) -= sum * t3;
-                    }
-                    for (int j = 0; j < n; j++) {
-                        double sum = Z_(j, k2) + v2 * Z_(j, k2 + 1) + v3 * Z_(j, k2 + 2);
-                        Z_(j, k2) -= sum * t1; Z_(j, k2 + 1) -= sum * t2; Z_(j, k2 + 2) -= sum * t3;
+                    {   // three distinct columns: restrict-qualified so that the loops vectorise
+                        double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1), *__restrict__ c2 = &T_(0, k2 + 2);
+                        for (int j = 0; j <= je; j++) {
+                            double sum = c0[j] + v2 * c1[j] + v3 * c2[j];
+                            c0[j] -= sum * t1; c1[j] -= sum * t2; c2[j] -= sum * t3;
+                        }
+                        double *__restrict__ z0 = &Z_(0, k2), *__restrict__ z1 = &Z_(0, k2 + 1), *__restrict__ z2 = &Z_(0, k2 + 2);
+                        for (int j = 0; j < n; j++) {
+                            double sum = z0[j] + v2 * z1[j] + v3 * z2[j];
+                            z0[j] -= sum * t1; z1[j] -= sum * t2; z2[j] -= sum * t3;
+                        }
                     }
                 } else {
                     for (int j = k2; j < n; j++) {
                         double sum = T_(k2, j) + v2 * T_(k2 + 1, j);
                         T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2;
                     }
+                    double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1);
                     for (int j = 0; j <= i; j++) {
-                        double sum = T_(j, k2) + v2 * T_(j, k2 + 1);
-                        T_(j, k2) -= sum * t1; T_(j, k2 + 1) -= sum * t2;
+                        double sum = c0[j] + v2 * c1[j];
+                        c0[j] -= sum * t1; c1[j] -= sum * t2;
                     }
+                    double *__restrict__ z0 = &Z_(0, k2), *__restrict__ z1 = &Z_(0, k2 + 1);
                     for (int j = 0; j < n; j++) {
-                        double sum = Z_(j, k2) + v2 * Z_(j, k2 + 1);
-                        Z_(j, k2) -= sum * t1; Z_(j, k2 + 1) -= sum * t2;
+                        double sum = z0[j] + v2 * z1[j];
+                        z0[j] -= sum * t1; z1[j] -= sum * t2;
                     }
                 }
             }
