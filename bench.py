@@ -123,8 +123,9 @@ def cpu_baseline(n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1,
+                    help="untimed steps (the first call allocates the cached workspaces and creates ~10^4 events)")
     ap.add_argument("--size", "--n", dest="n", type=int, default=20000)
     ap.add_argument("--cpu-n", type=int, default=1500, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--force-sharded", action="store_true",
