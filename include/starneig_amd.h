@@ -5,7 +5,8 @@
  * HBM -- what a caller that keeps its data on the GPU (or a benchmark that must
  * not time PCIe) binds instead.  Plain pointers and sizes only; `stream` is a
  * hipStream_t passed as void* (NULL = default stream).
- * All matrices are column-major doubles. */
+ * All matrices are column-major doubles.  Workspaces and internal streams are cached per
+ * process: the entry points are not reentrant (one reduction at a time per process). */
 #ifndef STARNEIG_AMD_H
 #define STARNEIG_AMD_H
 #include <starneig/error.h>
