@@ -186,3 +186,30 @@ def test_qz_device_resident_lcg_pencil(node, n):
     S, T = to_host(tH), to_host(tR)
     assert O.check_gep_schur_form(S, T) == 0
     assert st["sweeps"] > 0 and st["aeds"] > 0
+
+
+def test_qz_device_without_q_and_z(node):
+    """dQ = dZ = NULL (and only one of them): the pencil result does not depend on the accumulation"""
+    import torch
+    n = 1500
+    tH0, tR0 = node.device_matrix(n), node.device_matrix(n)
+    assert node.lcg_pencil_device(tH0, tR0, n, seed=7) == 0
+    ref = None
+    for use_q, use_z in ((True, True), (False, False), (True, False), (False, True)):
+        tH, tR = tH0.clone(), tR0.clone()
+        tQ = node.device_matrix(n) if use_q else None
+        tZ = node.device_matrix(n) if use_z else None
+        if tQ is not None:
+            node.set_matrix_device(tQ, n, n, 0.0, 1.0)
+        if tZ is not None:
+            node.set_matrix_device(tZ, n, n, 0.0, 1.0)
+        rc, ar, ai, be, _ = node.gep_schur_device(tH, tR, tQ, tZ, n=n)
+        assert rc == 0
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (tH, tR, ar, ai, be)
+            rc, ca = node.check_pencil_device(tQ, tH, tZ, tH0, n=n)
+            assert rc == 0 and ca["residual_u"] < WARN_U
+        else:
+            assert torch.equal(ref[0], tH) and torch.equal(ref[1], tR)
+            assert np.array_equal(ref[2], ar) and np.array_equal(ref[4], be)

@@ -238,3 +238,23 @@ def test_device_resident_chain_exercises_update_zones(node, n, conf_vals):
     S = to_host(results[0][0])
     assert O.check_schur_form(S) == 0
     assert abs(results[0][2].sum() - float(torch.diagonal(tA0[:, :n]).sum())) <= 1e-9 * n
+
+
+def test_device_schur_without_q(node):
+    """dQ = NULL: no accumulation (the lazy Q stream is idle); eigenvalues equal the run with Q"""
+    import torch
+    n = 3200
+    tA0 = node.device_matrix(n)
+    assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
+    tH0 = tA0.clone(); tQ0 = node.device_matrix(n)
+    node.set_matrix_device(tQ0, n, n, 0.0, 1.0)
+    assert node.hessenberg_device(tH0, tQ0, n=n) == 0
+    tH1, tQ1 = tH0.clone(), tQ0.clone()
+    rc, real1, imag1, _ = node.schur_device(tH1, tQ1, n=n)
+    assert rc == 0
+    tH2 = tH0.clone()
+    rc, real2, imag2, _ = node.schur_device(tH2, None, n=n)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(tH1, tH2)
+    assert np.array_equal(real1, real2) and np.array_equal(imag1, imag2)
