@@ -579,16 +579,16 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     // a sweep costs latency and accuracy (error ~ sqrt(number of window multiplications)), and
     // an AED with reordering deflates converged eigenvalues from anywhere in its window.  The
     // measured optimum is a SMALL window with a LOW nibble: at n = 12000 (test driver's random
-    // pencil) window 64 / nibble 8 % needs 850 AEDs of 1.8 ms and only 18 sweeps -- 2.2 s and a
-    // residual of 81 u, against 7.0 s and 499 u for window 160 / nibble 40 % (137 sweeps).
-    // If the AEDs stop deflating (less than 8 % of the window) the sweeps take over as usual.
+    // pencil) window 64 / nibble 6 % needs 880 AEDs of 1.8 ms and only 4 sweeps -- 1.9 s and a
+    // residual of 74 u, against 7.0 s and 499 u for window 160 / nibble 40 % (137 sweeps).
+    // If the AEDs stop deflating (less than 6 % of the window) the sweeps take over as usual.
     int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 768) : std::min(64, std::max(16, n / 8));
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : std::min(100, std::max(2, 2 * nw_conf / 3));
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
     ns_conf = std::max(2, ns_conf - ns_conf % 2);
     int const small_limit = prm.small_limit > 0 ? std::min(prm.small_limit, 768)
                                                 : std::max(GWS + 32, std::min(200, nw_conf));
-    int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 8;
+    int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 6;
     int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
 
     GepWorkspace &ws = g_gws;
