@@ -127,9 +127,24 @@ void gemm_tile(int m, int n, int k, double alpha,
         __syncthreads();
     }
 
-    // epilogue: lane holds C[r = .. + l15][c = .. + l4 + 4*reg]
+    // epilogue: lane holds C[r = .. + l15][c = .. + l4 + 4*reg].  With beta != 0 the old values of
+    // one column group are loaded together before any of them is overwritten: the loads are
+    // independent (one memory latency per group instead of one per element -- the stores of
+    // the plain loop may alias the next load, so the compiler cannot hoist it)
     #pragma unroll
     for (int ci = 0; ci < Cfg::TN; ci++) {
+        double old[Cfg::TM][4];
+        if (beta != 0.0) {
+            #pragma unroll
+            for (int ri = 0; ri < Cfg::TM; ri++) {
+                int r = r0 + wm * Cfg::WM + ri * 16 + l15;
+                #pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
+                    old[ri][reg] = (r < m && c < n) ? C[(size_t)c * ldc + r] : 0.0;
+                }
+            }
+        }
         #pragma unroll
         for (int ri = 0; ri < Cfg::TM; ri++) {
             int r = r0 + wm * Cfg::WM + ri * 16 + l15;
@@ -137,10 +152,9 @@ void gemm_tile(int m, int n, int k, double alpha,
             for (int reg = 0; reg < 4; reg++) {
                 int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
                 if (r < m && c < n) {
-                    double *p = C + (size_t)c * ldc + r;
                     double v = alpha * acc[ci][ri][reg];
-                    if (beta != 0.0) v += beta * (*p);
-                    *p = v;
+                    if (beta != 0.0) v += beta * old[ri][reg];
+                    C[(size_t)c * ldc + r] = v;
                 }
             }
         }
