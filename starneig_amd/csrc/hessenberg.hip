@@ -416,7 +416,7 @@ __global__ void hess_copy_out_kernel(int R0, int E, int nb, int i,
 
 // ---- workspace ----------------------------------------------------------------
 struct HessWorkspace {
-    int n = 0, nbmax = 0, ldp = 0;
+    int n = 0, nbmax = 0, ldp = 0, ysplits = 0;
     double *P = nullptr, *V[2] = {nullptr, nullptr}, *Y = nullptr, *VT[2] = {nullptr, nullptr};
     double *W = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
@@ -430,10 +430,11 @@ struct HessWorkspace {
     void release() {
         double **ptrs[] = {&P, &V[0], &V[1], &Y, &VT[0], &VT[1], &W, &W2, &ypart, &acc, &scal};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
-        n = nbmax = 0;
+        n = nbmax = 0; ysplits = 0;
     }
     void ensure(int n_, int nb_) {
-        if (n_ <= n && nb_ <= nbmax) return;
+        int const need_splits = std::max(MAX_SPLIT, divceil(n_, std::max(8, nb_)) + 1);
+        if (n_ <= n && nb_ <= nbmax && need_splits <= ysplits) return;
         release();
         n = n_; nbmax = nb_;
         ldp = (int)roundup((size_t)n + GEMV_ROWS + 16, 128);
@@ -445,7 +446,9 @@ struct HessWorkspace {
         alloc(&P, pan); alloc(&V[0], pan); alloc(&V[1], pan); alloc(&Y, pan);
         alloc(&VT[0], pan); alloc(&VT[1], pan);
         alloc(&W, pan); alloc(&W2, pan);
-        alloc(&ypart, (size_t)MAX_SPLIT * ldp * sizeof(double));
+        // one slice per column split of the gemv; the sharded path uses one per owned block column
+        ysplits = need_splits;
+        alloc(&ypart, (size_t)ysplits * ldp * sizeof(double));
         alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
         alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
         if (!side) {
@@ -713,9 +716,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             int nsplit = first > last_block ? 0 : (last_block - first) / world + 1;
             int const row_tiles = divceil(E - (R0 & ~1), GEMV_ROWS);
             int const nshadow = divceil(m, RBS);
-            // ypart has MAX_SPLIT slots: with more owned blocks than that the tail blocks are
-            // merged by widening the block (never happens for n/cb/world <= 32)
-            if (nsplit > MAX_SPLIT) return -2;
+            if (nsplit > ws.ysplits) return -2;        // (cannot happen: one slice per block column)
             dim3 grid(nshadow + row_tiles * std::max(nsplit, 0));
             if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
