@@ -10,8 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n,pw", [(2, 700, 64), (3, 1000, 96), (2, 333, 40), (2, 2600, 128)])
+@pytest.mark.parametrize("world,n,pw", [(2, 700, 64), (3, 1000, 96), (2, 333, 40), (2, 2600, 128), (2, 2700, 40)])
 def test_sharded_hessenberg_matches_single_gpu(world, n, pw):
+    # (2, 2700, 40): 68 block columns, 34 per rank -- more than the 32 column splits of the
+    # single-GPU gemv (the n = 20000 runs on 1 and 2 GPUs have 65 and 33)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + world * 7 + n % 97),
