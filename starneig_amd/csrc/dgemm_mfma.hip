@@ -21,6 +21,7 @@
 // bank-conflict free.
 #include "common.h"
 #include "dgemm_tile.h"
+#include <algorithm>
 
 namespace sn {
 
@@ -44,6 +45,22 @@ void dgemm_kernel(int m, int n, int k, double alpha,
     int const gsize = min(tiles_m - first_m, GROUP_M);
     int const bm = first_m + (pid % in_group) % gsize, bn = (pid % in_group) / gsize;
     gemm_tile<BM, BN, KT, TA, TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn);
+}
+
+// Split-K form for small outputs with a long inner dimension (W = A^T (V T) over one block
+// column of the sharded Hessenberg path: 312 x 312 output, k = trailing rows): blockIdx.y
+// selects a slice of k, the slices are summed into C (zeroed by the caller) with fp64 atomics.
+// Both operands are k-contiguous (TA, !TB), so a slice is a pointer offset.
+template <int BM, int BN, int KT>
+__global__ __launch_bounds__(256, 2)
+void dgemm_splitk_tn_kernel(int m, int n, int k, int kchunk, double alpha,
+    double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
+    double *__restrict__ C, int ldc, int tiles_m)
+{
+    int const k0 = blockIdx.y * kchunk, kl = min(kchunk, k - k0);
+    if (kl <= 0) return;
+    gemm_tile<BM, BN, KT, true, false>(m, n, kl, alpha, A + k0, lda, B + k0, ldb, 0.0, C, ldc,
+        blockIdx.x % tiles_m, blockIdx.x / tiles_m, true);
 }
 
 // Batched form: blockIdx.y selects a problem descriptor (alpha = 1, beta = 0).  Used for the
@@ -109,6 +126,27 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
     double const *A, int lda, double const *B, int ldb, double beta,
     double *C, int ldc)
 {
+    if (TA && !TB && beta == 0.0) {
+        // few output tiles, long k: split k over the chip (fp64 atomics; the order of the partial
+        // sums varies from run to run in the last bits, like the reference's STARPU_COMMUTE sums)
+        long const tiles64 = (long)divceil(m, 64) * divceil(n, 64);
+        if (tiles64 <= 64 && k >= 2048) {
+            using Cfg = GemmCfg<64, 64, 16, true, false>;
+            static bool attr_set = false;
+            auto kern = dgemm_splitk_tn_kernel<64, 64, 16>;
+            if (!attr_set) {
+                SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+                attr_set = true;
+            }
+            int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, 1024 / tiles64));
+            int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
+            SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s));
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles64, divceil(k, kchunk)), dim3(256), Cfg::LDS_BYTES, s,
+                m, n, k, kchunk, alpha, A, lda, B, ldb, C, ldc, divceil(m, 64));
+            return;
+        }
+    }
     // Narrow outputs (n = panel width, 280..312) waste less with 64-wide tiles;
     // few big tiles would also leave most of the 256 CUs idle.
     long tiles128 = (long)divceil(m, 128) * divceil(n, 128);

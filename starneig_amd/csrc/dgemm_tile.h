@@ -28,7 +28,7 @@ template <int BM, int BN, int KT, bool TA, bool TB>
 __device__ __forceinline__
 void gemm_tile(int m, int n, int k, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double beta, double *__restrict__ C, int ldc, int bm, int bn)
+    double beta, double *__restrict__ C, int ldc, int bm, int bn, bool atomic = false)
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -153,6 +153,7 @@ void gemm_tile(int m, int n, int k, double alpha,
                 int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
                 if (r < m && c < n) {
                     double v = alpha * acc[ci][ri][reg];
+                    if (atomic) { atomicAdd(&C[(size_t)c * ldc + r], v); continue; }    // split-K slice
                     if (beta != 0.0) v += beta * old[ri][reg];
                     C[(size_t)c * ldc + r] = v;
                 }

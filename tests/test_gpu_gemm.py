@@ -19,6 +19,8 @@ SHAPES = [
     ("N", "T", 1, 1, 1),
     ("N", "N", 16, 16, 4),
     ("N", "T", 1000, 1000, 312),    # 128x128 tile path
+    ("T", "N", 312, 300, 5001),     # split-K path (few output tiles, long k; beta = 0 only)
+    ("T", "N", 40, 33, 2500),
 ]
 
 
