@@ -122,9 +122,10 @@ def schur_sharded(tH, tQ, n=None, conf=None, group=None):
         real.ctypes.data, imag.ctypes.data, C.byref(conf) if conf is not None else None,
         torch.cuda.current_stream().cuda_stream, st)
     # tQ has shape (columns, ld): dimension 1 runs over the rows of the column-major matrix
-    tQ[:, :r0] = 0.0
-    tQ[:, r1:] = 0.0
-    dist.all_reduce(tQ, op=dist.ReduceOp.SUM, group=group)
+    if world > 1:
+        tQ[:, :r0] = 0.0
+        tQ[:, r1:] = 0.0
+        dist.all_reduce(tQ, op=dist.ReduceOp.SUM, group=group)
     stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
              "aed_host_s": st[6], "gpu_wait_s": st[7], "q_rows": (r0, r1)}
