@@ -320,9 +320,9 @@ struct SchurWorkspace {
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
-            SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&far, hipStreamNonBlocking, hi_prio));
             SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
             SN_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, lo_prio));
             for (int k = 0; k < EV_RING; k++) {
@@ -334,7 +334,8 @@ struct SchurWorkspace {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&h_done[k], hipEventDisableTiming));
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
-            SN_HIP_CHECK(hipStreamCreateWithFlags(&aed, hipStreamNonBlocking));
+            // (high priority: a hardware-queue pool of its own, see schur_device)
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&aed, hipStreamNonBlocking, hi_prio));
             SN_HIP_CHECK(hipEventCreateWithFlags(&aed_mark, hipEventDisableTiming));
             for (int k = 0; k < Z_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&z_ready[k], hipEventDisableTiming));
@@ -712,7 +713,14 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     static hipStream_t own = nullptr;
     static hipEvent_t fence = nullptr;
     if (!own) {
-        SN_HIP_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+        // The critical stream gets the highest priority.  Besides the scheduling preference this
+        // puts it into another pool of hardware queues than the far and lazy streams: the runtime
+        // multiplexes streams of one priority onto a few hardware queues, and with other streams
+        // around (an RCCL communicator costs the reduction 0.8 s otherwise) the chase kernels would
+        // queue behind lazy updates.
+        int lo_prio = 0, hi_prio = 0;
+        SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        SN_HIP_CHECK(hipStreamCreateWithPriority(&own, hipStreamNonBlocking, hi_prio));
         SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
     }
     hipStream_t s = own;

@@ -315,9 +315,10 @@ struct GepWorkspace {
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, GEP_CHASE_LDS_BYTES));
-            SN_HIP_CHECK(hipStreamCreateWithFlags(&far, hipStreamNonBlocking));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&far, hipStreamNonBlocking, hi_prio));   // see schur.hip
+
             SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
             SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
             for (int k = 0; k < FLUSH_RING; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&q_done[k], hipEventDisableTiming));
@@ -568,7 +569,9 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     static hipStream_t own = nullptr;
     static hipEvent_t fence = nullptr;
     if (!own) {
-        SN_HIP_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+        int lo_prio = 0, hi_prio = 0;          // highest priority: see schur.hip
+        SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        SN_HIP_CHECK(hipStreamCreateWithPriority(&own, hipStreamNonBlocking, hi_prio));
         SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
     }
     hipStream_t s = own;
