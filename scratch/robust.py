@@ -16,7 +16,7 @@ def run(name, H0):
     form = O.check_schur_form(np.asfortranarray(H))
     print(f"{name:34s} n={n:5d} rc={rc} form={form} res={res:8.1f}u orth={orth:8.1f}u t={dt:.2f}s", flush=True)
 rng = np.random.RandomState(0)
-n = 600
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 run("orthogonal Hessenberg", sl.hessenberg(sl.qr(rng.randn(n, n))[0]))
 run("companion (z^n - 1)", np.eye(n, k=-1) + np.eye(n)[:, [0]] @ np.eye(n)[[n-1], :])
 c = np.eye(n, k=-1); c[0, :] = rng.randn(n) * 1e-3; run("companion random", c)

@@ -549,6 +549,7 @@ struct Driver {
         int col_split = 0;          // columns >= col_split are lazy for the steps being issued
     } sw;
     double sweep_flops = 0.0; int sweep_launches = 0;
+    long chain_passes = 0;      // chains over all sweeps: the rounding error grows like its square root
     int lazy_batch = getenv("SN_SCHUR_LAZY_BATCH") ? atoi(getenv("SN_SCHUR_LAZY_BATCH")) : 32;
 
     void sweep_begin(int ilo, int ihi, int nshifts, double const *sr, double const *si)
@@ -565,6 +566,7 @@ struct Driver {
         sw.active = true;
         sw.ilo = ilo; sw.ihi = ihi; sw.ws_ = ws_; sw.nbc = nbc; sw.nbulges = nbulges;
         sw.chains = divceil(nbulges, nbc);
+        chain_passes += sw.chains;
         sw.adv = ws_ - 1 - 3 * nbc;                           // columns a chain advances per step
         // chains ws+adv rows apart: a chain's next window then depends on its OWN near update only
         sw.gap = (sw.adv > 0) ? divceil(ws_ + sw.adv, sw.adv) : 1;
@@ -754,7 +756,13 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // chains only add `gap` steps each, so the same shifts applied 8x cost ~1.3x the time of a
     // sweep and cut the number of sweeps at n = 20000 from 81 to 13 (measured: 7.0 s -> 5.4 s at
     // a 192-row AED window).
-    static int const reuse = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 8;
+    // The extra chain passes cost accuracy (orthogonality error ~ sqrt(chain passes): on slowly
+    // converging structured matrices -- all-ones Hessenberg, Toeplitz tridiagonal, n = 2600 --
+    // the residual is 260 / 440 / 780 u at multiplicity 1 / 4 / 8) and buy little where sweeps are
+    // short anyway, so the multiplicity grows with the size: 2 below n = 4000, 4 below 12000, 8
+    // above.  SN_SCHUR_REUSE=k overrides.
+    static int const reuse_env = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 0;
+    int const reuse = reuse_env ? reuse_env : (n < 4000 ? 2 : (n < 12000 ? 4 : 8));
     ws.ensure(n, wmax, divceil(reuse * (ns_conf / 2), NB_MAX) + 2);
     ws.guard_row = 0;
     Driver d{s, n, dH, ldH, dQ, ldQ, ws, SchurStats{}};
@@ -960,8 +968,9 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
     if (getenv("SN_SCHUR_PROFILE"))
-        fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d\n",
-            d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves);
+        fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d; n %d sweeps %d aeds %d chain passes %ld\n",
+            d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves,
+            n, d.st.sweeps, d.st.aeds, d.chain_passes);
     if (stats) *stats = d.st;
     return rc;
 }
