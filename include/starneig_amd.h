@@ -17,11 +17,14 @@ extern "C" {
 /* Replaces starneig_hessenberg_insert_tasks (hessenberg/core.c:351) + codelets
  * (hessenberg/cpu.c:50-560, cuda.cu:62-309) on device-resident data.
  * panel_width <= 0 selects the reference default (hessenberg/interface.c:74-78).
- * dQ may be NULL (Q not accumulated).  stats (may be NULL) is double[8]:
+ * dQ may be NULL (Q not accumulated).  stats (may be NULL) is double[16]:
  * in  [7] = k > 0: time every k-th panel-gemv launch with HIP events (0 = off);
  * out [0] total ms (events on `stream`), [1] algorithmic bytes of all panel-gemv
  * launches, [2] executed GEMM flops, [3] summed duration (ms) and [4] algorithmic
- * bytes of the sampled gemv launches, [5] gemv launches, [6] sampled launches.
+ * bytes of the sampled gemv launches, [5] gemv launches, [6] sampled launches,
+ * [8] summed duration (ms, HIP events on the critical stream) and [9] executed flops of
+ * the trailing-matrix updates (rows H4-H6), [10] summed duration (ms) of the delayed
+ * updates of Q and the upper rows on the side stream ([2] - [9] flops).
  * Blocks until the result is complete. */
 starneig_error_t starneig_amd_hessenberg_device(
     int n, int begin, int end, int panel_width,

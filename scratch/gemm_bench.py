@@ -26,3 +26,8 @@ bench("N", "N", 8192, 8192, 8192, 0.0, reps=10)
 bench("N", "N", 8192, 8192, 8192, 0.0, reps=10, zero=True)
 bench("N", "T", 20000, 20000, 312)
 bench("N", "T", 20000, 20000, 312, zero=True)
+bench("N", "T", 20000, 20000, 624)                  # fused trailing update A -= [Y V][V' W]^T
+bench("N", "T", 10000, 10000, 624)
+bench("T", "N", 20000, 312, 20000, 0.0)             # W = A^T (V T)  (split-K)
+bench("N", "N", 20000, 312, 20000, 0.0)             # W = Q (V T)    (split-K)
+bench("N", "T", 20000, 20000, 312)                  # Q -= W V^T

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <sched.h>
 #include <starneig/starneig.h>
 #include <starneig_amd.h>
 
@@ -23,7 +24,7 @@ namespace {
 
 struct NodeState {                      // reference: static state, common/node.c:61-92
     bool initialized = false;
-    int cores = 0, gpus = 0;
+    int cores = 0, gpus = 0, avail_cores = 1;
     bool messages = true, verbose = true, pinning = false;
     int device = 0;
 } g_node;
@@ -67,19 +68,38 @@ SN_API void starneig_node_init(int cores, int gpus, starneig_flag_t flags)
     g_node.verbose = !(flags & STARNEIG_NO_VERBOSE);
     g_node.messages = (flags & STARNEIG_NO_MESSAGES) != STARNEIG_NO_MESSAGES;
     require_device();
-    g_node.cores = cores == STARNEIG_USE_ALL ? 1 : std::max(1, cores);
-    // one process drives one GPU; `gpus` other than 1 is accepted for interface
-    // compatibility (multi-GPU runs are one process per GPU over RCCL)
+    // cores: host threads available to the sequential window kernels (the process' affinity
+    // mask, like the hwloc binding mask of common/node.c:497-536); gpus: one process drives ONE
+    // device (multi-GPU runs are one process per GPU over RCCL), so any request other than 0
+    // resolves to 1 and 0 is refused -- there is no CPU path to fall back to.
+    cpu_set_t mask;
+    int avail = 1;
+    if (sched_getaffinity(0, sizeof mask, &mask) == 0) avail = std::max(1, CPU_COUNT(&mask));
+    g_node.avail_cores = avail;
+    g_node.cores = cores == STARNEIG_USE_ALL ? avail : std::max(1, std::min(cores, avail));
+    if (gpus == 0) {
+        fprintf(stderr, "[starneig-amd] fatal: starneig_node_init(gpus = 0): this library has no "
+            "CPU path.\n");
+        abort();
+    }
     g_node.gpus = 1;
-    (void)gpus;
     g_node.initialized = true;
 }
 
 SN_API int starneig_node_initialized(void) { return g_node.initialized ? 1 : 0; }
 SN_API int starneig_node_get_cores(void) { return g_node.cores; }
-SN_API void starneig_node_set_cores(int cores) { g_node.cores = std::max(1, cores); }
+SN_API void starneig_node_set_cores(int cores)
+{
+    g_node.cores = cores == STARNEIG_USE_ALL ? g_node.avail_cores
+                                             : std::max(1, std::min(cores, g_node.avail_cores));
+}
 SN_API int starneig_node_get_gpus(void) { return g_node.gpus; }
-SN_API void starneig_node_set_gpus(int gpus) { (void)gpus; g_node.gpus = 1; }
+SN_API void starneig_node_set_gpus(int gpus)
+{
+    if (gpus == 0 && g_node.messages)
+        fprintf(stderr, "[starneig-amd] warning: starneig_node_set_gpus(0) ignored: no CPU path.\n");
+    g_node.gpus = 1;
+}
 SN_API void starneig_node_enable_pinning(void) { g_node.pinning = true; }
 SN_API void starneig_node_disable_pinning(void) { g_node.pinning = false; }
 
@@ -183,29 +203,63 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg(
     return starneig_SEP_SM_Hessenberg_expert(NULL, n, 0, n, A, ldA, Q, ldQ);
 }
 
-// schur/process_args.c:278-437: range checks of the expert configuration
-static int schur_params_from_conf(struct starneig_schur_conf const *conf, sn::SchurParams &p)
+// Expert configuration -> SchurParams with the reference's range checks, in the reference's
+// order: thresholds first (schur/core.c:2360-2384 -> STARNEIG_INVALID_CONFIGURATION), then
+// schur/process_args.c:271-437 (-> STARNEIG_INVALID_ARGUMENTS).  Fields that describe the
+// reference's tile/task organisation (tile_size, window_size, update_width/height,
+// shift_origin -- unused by the reference as well) are range-checked exactly like there and
+// then have no effect: H and Q are untiled here and the bulge window is fixed by the LDS of
+// a CU.  shifts_per_window caps the bulges per chain; aed_parallel_hard_limit selects the
+// host kernel below / the blocked device kernel above it (process_args.c:372-398).
+static int schur_params_from_conf(struct starneig_schur_conf const *conf, sn::SchurParams &p,
+    bool generalized)
 {
     if (conf == NULL) return STARNEIG_SUCCESS;
-    auto bad_int = [](int v) { return v != -1 && v < 1; };
-    if (bad_int(conf->iteration_limit) || bad_int(conf->small_limit) ||
-        bad_int(conf->aed_window_size) || bad_int(conf->shift_count) ||
-        (conf->tile_size != -1 && conf->tile_size < 8))
+    auto bad_thres = [](double t, bool lapack_ok) {
+        return !(t == -1.0 || t == -2.0 || (lapack_ok && t == -3.0) || t > 0.0);
+    };
+    if (bad_thres(conf->left_threshold, true) || bad_thres(conf->right_threshold, true) ||
+        bad_thres(conf->inf_threshold, false))
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->iteration_limit != -1 && conf->iteration_limit <= 0) return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->small_limit != -1 && conf->small_limit <= 2) return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_window_size == -1 && conf->shift_count != -1 && conf->shift_count < 2)
         return STARNEIG_INVALID_ARGUMENTS;
-    if (conf->aed_nibble != -1 && (conf->aed_nibble < 1 || conf->aed_nibble > 99))
+    if (conf->aed_window_size != -1 && conf->shift_count == -1 && conf->aed_window_size <= 4)
         return STARNEIG_INVALID_ARGUMENTS;
-    if (conf->aed_window_size > 0 && conf->shift_count > 0 &&
+    if (conf->aed_window_size != -1 && conf->shift_count != -1 &&
         conf->shift_count > conf->aed_window_size)
-        return STARNEIG_INVALID_ARGUMENTS;          // process_args.c:340-352
-    double lt = conf->left_threshold;
-    if (!(lt == -1.0 || lt == -2.0 || lt == -3.0 || lt > 0.0))
-        return STARNEIG_INVALID_CONFIGURATION;      // schur/core.c:2360-2384
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_nibble != -1 && (conf->aed_nibble <= 0 || conf->aed_nibble >= 100))
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_parallel_soft_limit != -1 && conf->aed_parallel_soft_limit <= 0)
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->aed_parallel_hard_limit != -1 && conf->aed_parallel_hard_limit <= 0)
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->window_size != -1 && conf->window_size != -2 && conf->window_size < 5)
+        return STARNEIG_INVALID_ARGUMENTS;
+    if (conf->shifts_per_window != -1 && conf->shifts_per_window < 2)
+        return STARNEIG_INVALID_ARGUMENTS;
+    // (update_width / update_height <= 0: the reference warns and uses its default, :440-500)
     p.iteration_limit = conf->iteration_limit;
     p.small_limit = conf->small_limit;
-    p.aed_window_size = conf->aed_window_size;
     p.aed_nibble = conf->aed_nibble;
-    p.shift_count = conf->shift_count;
-    p.threshold = lt;
+    // process_args.c:294-352: a lone shift count implies a window of twice that size, a lone
+    // window implies half as many shifts, both: shifts <= 0.9 window
+    if (conf->aed_window_size == -1 && conf->shift_count != -1) {
+        p.aed_window_size = 2 * conf->shift_count; p.shift_count = conf->shift_count;
+    } else if (conf->aed_window_size != -1 && conf->shift_count == -1) {
+        p.aed_window_size = conf->aed_window_size; p.shift_count = conf->aed_window_size / 2;
+    } else if (conf->aed_window_size != -1) {
+        p.aed_window_size = conf->aed_window_size;
+        p.shift_count = std::min(9 * conf->aed_window_size / 10, conf->shift_count);
+    }
+    p.shifts_per_window = conf->shifts_per_window;
+    p.aed_parallel_hard_limit = conf->aed_parallel_hard_limit;
+    p.threshold = conf->left_threshold;
+    p.threshold_b = conf->right_threshold;
+    p.threshold_inf = conf->inf_threshold;
+    (void)generalized;
     return STARNEIG_SUCCESS;
 }
 
@@ -220,7 +274,7 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
     if (ldQ < n)    return -6;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     sn::SchurParams prm;
-    int rc = schur_params_from_conf(conf, prm);
+    int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
 
     int const ld = (int)sn::roundup(n, 16);
@@ -276,7 +330,9 @@ SN_API starneig_error_t starneig_SEP_SM_Select(
     sn::host::extract_eigenvalues(n, S, ldS, wr.data(), wi.data());
     int count = 0;
     for (int i = 0; i < n; i++) {
-        if (wi[i] != 0.0 && i + 1 < n) {            // a 2x2 block: both or none
+        // a 2x2 block (S(i+1,i) != 0, also a non-standardised one with real eigenvalues) is
+        // selected or rejected as a whole, by its first eigenvalue (common/helpers.c:70-93)
+        if (i + 1 < n && S[(size_t)i * ldS + i + 1] != 0.0) {
             int sel = predicate(wr[i], wi[i], arg) ? 1 : 0;
             selected[i] = selected[i + 1] = sel;
             count += 2 * sel;
@@ -300,9 +356,7 @@ SN_API starneig_error_t starneig_SEP_SM_Reduce(
     if (A == NULL)  return -2;
     if (ldA < n)    return -3;
     if (Q == NULL)  return -4;
-    if (ldQ < n)    return -5;
-    if (real == NULL) return -6;
-    if (imag == NULL) return -7;
+    if (ldQ < n)    return -5;           // common/combined.c:57-61: nothing beyond -5
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     if (predicate != NULL) return STARNEIG_GENERIC_ERROR;   // reordering is outside this path
     (void)arg; (void)selected;
@@ -328,7 +382,7 @@ SN_API starneig_error_t starneig_GEP_SM_Schur_expert(
     if (ldZ < n)    return -10;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     sn::SchurParams prm;
-    int rc = schur_params_from_conf(conf, prm);
+    int rc = schur_params_from_conf(conf, prm, true);
     if (rc != STARNEIG_SUCCESS) return rc;
 
     int const ld = (int)sn::roundup(n, 16);
@@ -366,10 +420,8 @@ SN_API starneig_error_t starneig_GEP_SM_Schur(
     if (Q == NULL)  return -6;
     if (ldQ < n)    return -7;
     if (Z == NULL)  return -8;
-    if (ldZ < n)    return -9;
-    if (real == NULL) return -10;
-    if (imag == NULL) return -11;
-    if (beta == NULL) return -12;
+    if (ldZ < n)    return -9;           // schur/interface.c:286-294: nothing beyond -9
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     return starneig_GEP_SM_Schur_expert(NULL, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta);
 }
 
@@ -389,7 +441,7 @@ SN_API starneig_error_t starneig_amd_gep_schur_device(
     if (dZ != NULL && ldZ < n) return -9;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     sn::SchurParams prm;
-    int rc = schur_params_from_conf(conf, prm);
+    int rc = schur_params_from_conf(conf, prm, true);
     if (rc != STARNEIG_SUCCESS) return rc;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
@@ -414,7 +466,7 @@ SN_API starneig_error_t starneig_amd_schur_device(
     if (dQ != NULL && ldQ < n) return -5;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     sn::SchurParams prm;
-    int rc = schur_params_from_conf(conf, prm);
+    int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
@@ -441,7 +493,7 @@ SN_API starneig_error_t starneig_amd_schur_rows_device(
     if (q_rows < 0 || q_rows > n) return -6;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     sn::SchurParams prm;
-    int rc = schur_params_from_conf(conf, prm);
+    int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
@@ -479,6 +531,7 @@ SN_API starneig_error_t starneig_amd_hessenberg_device(
         stats[0] = tm.total_ms; stats[1] = tm.gemv_bytes; stats[2] = tm.gemm_flops;
         stats[3] = tm.sampled_ms; stats[4] = tm.sampled_bytes;
         stats[5] = (double)tm.gemv_launches; stats[6] = (double)tm.sampled_launches;
+        stats[8] = tm.gemm_ms_main; stats[9] = tm.gemm_flops_main; stats[10] = tm.gemm_ms_side;
     }
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 }

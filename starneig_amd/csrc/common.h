@@ -56,6 +56,9 @@ struct HessenbergTimings {
     float total_ms = 0.f;       // whole reduction, event-timed on the caller's stream
     double gemv_bytes = 0.0;    // algorithmic bytes streamed by all panel gemv launches
     double gemm_flops = 0.0;    // executed GEMM flops (all updates)
+    double gemm_flops_main = 0.0;   // of which: the critical trailing update (rows H4-H6)
+    double gemm_ms_main = 0.0;      // its summed duration (events on the critical stream)
+    double gemm_ms_side = 0.0;      // summed duration of the delayed updates (Q, upper rows) on the side stream
     long gemv_launches = 0;
     long sampled_launches = 0;
     double sampled_bytes = 0.0; // algorithmic bytes of the sampled launches
@@ -90,6 +93,10 @@ struct SchurParams {            // resolved from starneig_schur_conf (negative =
     int aed_nibble = -1;
     int shift_count = -1;
     double threshold = -1.0;    // -1/-2: norm-stable (u*||H||_F), -3: LAPACK criterion, >0: absolute
+    int shifts_per_window = -1; // caps the shifts (2 x bulges) of one chain
+    int aed_parallel_hard_limit = -1;   // AED windows up to this size use the sequential host kernel
+    double threshold_b = -1.0;  // pencils: deflation threshold of B (right_threshold)
+    double threshold_inf = -1.0;// pencils: infinite-eigenvalue threshold (inf_threshold)
 };
 struct SchurStats {
     int sweeps = 0, aeds = 0, small_solves = 0, chase_launches = 0;

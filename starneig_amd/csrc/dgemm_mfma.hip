@@ -47,19 +47,22 @@ void dgemm_kernel(int m, int n, int k, double alpha,
     gemm_tile<BM, BN, KT, TA, TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn);
 }
 
-// Split-K form for small outputs with a long inner dimension (W = A^T (V T) over one block
-// column of the sharded Hessenberg path: 312 x 312 output, k = trailing rows): blockIdx.y
-// selects a slice of k, the slices are summed into C (zeroed by the caller) with fp64 atomics.
-// Both operands are k-contiguous (TA, !TB), so a slice is a pointer offset.
-template <int BM, int BN, int KT>
+// Split-K form for outputs with few tiles and a long inner dimension (the inner-product shaped
+// GEMMs of the Hessenberg path: W = A^T (V T), W = X (V T), S = Y^T (V T) -- skinny n = panel
+// width, k = trailing rows): blockIdx.y selects a slice of k, the slices are summed into C
+// (zeroed by the caller) with fp64 atomics.  Besides filling the chip this shortens the
+// sequential accumulation chains from k to k / slices terms.
+template <int BM, int BN, int KT, bool TA, bool TB>
 __global__ __launch_bounds__(256, 2)
-void dgemm_splitk_tn_kernel(int m, int n, int k, int kchunk, double alpha,
+void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
     double *__restrict__ C, int ldc, int tiles_m)
 {
     int const k0 = blockIdx.y * kchunk, kl = min(kchunk, k - k0);
     if (kl <= 0) return;
-    gemm_tile<BM, BN, KT, true, false>(m, n, kl, alpha, A + k0, lda, B + k0, ldb, 0.0, C, ldc,
+    double const *Ak = TA ? A + k0 : A + (size_t)k0 * lda;
+    double const *Bk = TB ? B + (size_t)k0 * ldb : B + k0;
+    gemm_tile<BM, BN, KT, TA, TB>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc,
         blockIdx.x % tiles_m, blockIdx.x / tiles_m, true);
 }
 
@@ -121,30 +124,49 @@ static void launch(hipStream_t s, int m, int n, int k, double alpha,
         m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tiles_m);
 }
 
+template <int BM, int BN, bool TA, bool TB>
+static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double alpha,
+    double const *A, int lda, double const *B, int ldb, double *C, int ldc)
+{
+    using Cfg = GemmCfg<BM, BN, 16, TA, TB>;
+    static bool attr_set = false;
+    auto kern = dgemm_splitk_kernel<BM, BN, 16, TA, TB>;
+    if (!attr_set) {
+        SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
+            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
+    int const tiles_m = divceil(m, BM), tiles = tiles_m * divceil(n, BN);
+    SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, divceil(k, kchunk)), dim3(256), Cfg::LDS_BYTES, s,
+        m, n, k, kchunk, alpha, A, lda, B, ldb, C, ldc, tiles_m);
+}
+
 template <bool TA, bool TB>
 static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
     double const *A, int lda, double const *B, int ldb, double beta,
     double *C, int ldc)
 {
-    if (TA && !TB && beta == 0.0) {
-        // few output tiles, long k: split k over the chip (fp64 atomics; the order of the partial
-        // sums varies from run to run in the last bits, like the reference's STARPU_COMMUTE sums)
-        long const tiles64 = (long)divceil(m, 64) * divceil(n, 64);
-        if (tiles64 <= 64 && k >= 2048) {
-            using Cfg = GemmCfg<64, 64, 16, true, false>;
-            static bool attr_set = false;
-            auto kern = dgemm_splitk_tn_kernel<64, 64, 16>;
-            if (!attr_set) {
-                SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-                attr_set = true;
-            }
-            int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, 1024 / tiles64));
-            int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
-            SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s));
-            hipLaunchKernelGGL(kern, dim3((unsigned)tiles64, divceil(k, kchunk)), dim3(256), Cfg::LDS_BYTES, s,
-                m, n, k, kchunk, alpha, A, lda, B, ldb, C, ldc, divceil(m, 64));
+    // (only inner-product shapes, min(m,n) << k: the square window products of the Schur path must
+    // stay deterministic -- replicas of one reduction on several GPUs rely on it)
+    if (beta == 0.0 && k >= 2048 && (long)std::min(m, n) * 4 <= k) {
+        // Few output tiles, long k: split k over the chip (fp64 atomics; the order of the partial
+        // sums varies from run to run in the last bits, like the reference's STARPU_COMMUTE sums).
+        // Target: ~6 work items per workgroup slot (256 CUs x 2), slices of >= 512.
+        long const t128 = (long)divceil(m, 128) * divceil(n, 64);
+        long const t64 = (long)divceil(m, 64) * divceil(n, 64);
+        if (t64 <= 64) {
+            int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, 1024 / t64));
+            launch_splitk<64, 64, TA, TB>(s, m, n, k, slices, alpha, A, lda, B, ldb, C, ldc);
             return;
+        }
+        if (t128 < 2048) {
+            int const slices = (int)std::min<long>(divceil(k, 512), divceil(3072, (int)t128));
+            if (slices > 1) {
+                launch_splitk<128, 64, TA, TB>(s, m, n, k, slices, alpha, A, lda, B, ldb, C, ldc);
+                return;
+            }
         }
     }
     // Narrow outputs (n = panel width, 280..312) waste less with 64-wide tiles;

@@ -6,6 +6,8 @@
 namespace sn {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef d2 d2u __attribute__((aligned(8)));      // 16-byte global loads from 8-byte aligned addresses
 
 template <int BM, int BN, int KT, bool TA, bool TB>
 struct GemmCfg {
@@ -41,45 +43,87 @@ void gemm_tile(int m, int n, int k, double alpha,
 
     double rreg[Cfg::R_LOADS], creg[Cfg::C_LOADS];
 
+    // C <- C + alpha op(A) op(B) with alpha = +-1 (the rank-k updates of the Hessenberg path): the
+    // accumulators START as the old C tile and the column operand carries the sign, so the tile
+    // is read while the first operand tiles are in flight and the epilogue is stores only --
+    // instead of a dependent load / fma / store tail after the last MFMA.
+    bool const accinit = !atomic && beta == 1.0 && (alpha == 1.0 || alpha == -1.0);
+    double const opscale = accinit ? alpha : 1.0;
+    // interior tiles: straight 16-byte loads, no per-element bounds tests
+    bool const tile_full = (r0 + BM <= m) && (c0 + BN <= n);
+
     auto load_tiles = [&](int k0) {
-        #pragma unroll
-        for (int s = 0; s < Cfg::R_LOADS; s++) {
-            int e = tid + s * 256;
-            int mn, kk;
-            if (TA) { kk = e % KT; mn = e / KT; } else { mn = e % BM; kk = e / BM; }
-            int r = r0 + mn, kg = k0 + kk;
-            double v = 0.0;
-            if (r < m && kg < k)
-                v = TA ? A[(size_t)r * lda + kg] : A[(size_t)kg * lda + r];
-            rreg[s] = v;
+        if (tile_full && k0 + KT <= k) {
+            #pragma unroll
+            for (int s = 0; s < Cfg::R_LOADS / 2; s++) {
+                int e = tid + s * 256;
+                d2u v;
+                if (TA) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2);
+                          v = *reinterpret_cast<d2u const *>(A + (size_t)(r0 + mn) * lda + k0 + kk); }
+                else    { int mn = (e % (BM / 2)) * 2, kk = e / (BM / 2);
+                          v = *reinterpret_cast<d2u const *>(A + (size_t)(k0 + kk) * lda + r0 + mn); }
+                rreg[2 * s] = v.x; rreg[2 * s + 1] = v.y;
+            }
+            #pragma unroll
+            for (int s = 0; s < Cfg::C_LOADS / 2; s++) {
+                int e = tid + s * 256;
+                d2u v;
+                if (!TB) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2);
+                           v = *reinterpret_cast<d2u const *>(B + (size_t)(c0 + mn) * ldb + k0 + kk); }
+                else     { int mn = (e % (BN / 2)) * 2, kk = e / (BN / 2);
+                           v = *reinterpret_cast<d2u const *>(B + (size_t)(k0 + kk) * ldb + c0 + mn); }
+                creg[2 * s] = v.x * opscale; creg[2 * s + 1] = v.y * opscale;
+            }
+            return;
         }
         #pragma unroll
-        for (int s = 0; s < Cfg::C_LOADS; s++) {
-            int e = tid + s * 256;
-            int mn, kk;
-            if (!TB) { kk = e % KT; mn = e / KT; } else { mn = e % BN; kk = e / BN; }
-            int c = c0 + mn, kg = k0 + kk;
-            double v = 0.0;
-            if (c < n && kg < k)
-                v = TB ? B[(size_t)kg * ldb + c] : B[(size_t)c * ldb + kg];
-            creg[s] = v;
+        for (int s = 0; s < Cfg::R_LOADS / 2; s++) {
+            #pragma unroll
+            for (int h = 0; h < 2; h++) {
+                int e = tid + s * 256;
+                int mn, kk;
+                if (TA) { kk = (e % (KT / 2)) * 2 + h; mn = e / (KT / 2); }
+                else    { mn = (e % (BM / 2)) * 2 + h; kk = e / (BM / 2); }
+                int r = r0 + mn, kg = k0 + kk;
+                double v = 0.0;
+                if (r < m && kg < k)
+                    v = TA ? A[(size_t)r * lda + kg] : A[(size_t)kg * lda + r];
+                rreg[2 * s + h] = v;
+            }
+        }
+        #pragma unroll
+        for (int s = 0; s < Cfg::C_LOADS / 2; s++) {
+            #pragma unroll
+            for (int h = 0; h < 2; h++) {
+                int e = tid + s * 256;
+                int mn, kk;
+                if (!TB) { kk = (e % (KT / 2)) * 2 + h; mn = e / (KT / 2); }
+                else     { mn = (e % (BN / 2)) * 2 + h; kk = e / (BN / 2); }
+                int c = c0 + mn, kg = k0 + kk;
+                double v = 0.0;
+                if (c < n && kg < k)
+                    v = TB ? B[(size_t)kg * ldb + c] : B[(size_t)c * ldb + kg];
+                creg[2 * s + h] = v * opscale;
+            }
         }
     };
     auto store_tiles = [&](int buf) {
         double *dR = smem + buf * BUF_ELEMS, *dC = dR + Cfg::R_ELEMS;
         #pragma unroll
-        for (int s = 0; s < Cfg::R_LOADS; s++) {
+        for (int s = 0; s < Cfg::R_LOADS / 2; s++) {
             int e = tid + s * 256;
-            int mn, kk;
-            if (TA) { kk = e % KT; mn = e / KT; dR[mn * Cfg::LDR + kk] = rreg[s]; }
-            else    { mn = e % BM; kk = e / BM; dR[kk * Cfg::LDR + mn] = rreg[s]; }
+            double *d;
+            if (TA) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2); d = dR + mn * Cfg::LDR + kk; }
+            else    { int mn = (e % (BM / 2)) * 2, kk = e / (BM / 2); d = dR + kk * Cfg::LDR + mn; }
+            *reinterpret_cast<d2 *>(d) = (d2){rreg[2 * s], rreg[2 * s + 1]};
         }
         #pragma unroll
-        for (int s = 0; s < Cfg::C_LOADS; s++) {
+        for (int s = 0; s < Cfg::C_LOADS / 2; s++) {
             int e = tid + s * 256;
-            int mn, kk;
-            if (!TB) { kk = e % KT; mn = e / KT; dC[mn * Cfg::LDC + kk] = creg[s]; }
-            else     { mn = e % BN; kk = e / BN; dC[kk * Cfg::LDC + mn] = creg[s]; }
+            double *d;
+            if (!TB) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2); d = dC + mn * Cfg::LDC + kk; }
+            else     { int mn = (e % (BN / 2)) * 2, kk = e / (BN / 2); d = dC + kk * Cfg::LDC + mn; }
+            *reinterpret_cast<d2 *>(d) = (d2){creg[2 * s], creg[2 * s + 1]};
         }
     };
 
@@ -93,6 +137,19 @@ void gemm_tile(int m, int n, int k, double alpha,
     int const l15 = lane & 15, l4 = lane >> 4;
     int const nkt = (k + KT - 1) / KT;
 
+    if (accinit) {
+        #pragma unroll
+        for (int ci = 0; ci < Cfg::TN; ci++)
+            #pragma unroll
+            for (int ri = 0; ri < Cfg::TM; ri++) {
+                int r = r0 + wm * Cfg::WM + ri * 16 + l15;
+                #pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
+                    if (tile_full || (r < m && c < n)) acc[ci][ri][reg] = C[(size_t)c * ldc + r];
+                }
+            }
+    }
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -131,6 +188,20 @@ void gemm_tile(int m, int n, int k, double alpha,
     // one column group are loaded together before any of them is overwritten: the loads are
     // independent (one memory latency per group instead of one per element -- the stores of
     // the plain loop may alias the next load, so the compiler cannot hoist it)
+    if (accinit) {
+        #pragma unroll
+        for (int ci = 0; ci < Cfg::TN; ci++)
+            #pragma unroll
+            for (int ri = 0; ri < Cfg::TM; ri++) {
+                int r = r0 + wm * Cfg::WM + ri * 16 + l15;
+                #pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
+                    if (tile_full || (r < m && c < n)) C[(size_t)c * ldc + r] = acc[ci][ri][reg];
+                }
+            }
+        return;
+    }
     #pragma unroll
     for (int ci = 0; ci < Cfg::TN; ci++) {
         double old[Cfg::TM][4];

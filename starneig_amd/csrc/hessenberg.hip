@@ -417,18 +417,21 @@ __global__ void hess_copy_out_kernel(int R0, int E, int nb, int i,
 // ---- workspace ----------------------------------------------------------------
 struct HessWorkspace {
     int n = 0, nbmax = 0, ldp = 0, ysplits = 0;
-    double *P = nullptr, *V[2] = {nullptr, nullptr}, *Y = nullptr, *VT[2] = {nullptr, nullptr};
-    double *W = nullptr, *W2 = nullptr;
+    // YVW[b] = [ Y | V | W ] of one panel, three blocks of nb columns side by side with one leading
+    // dimension: the fused trailing update A -= [Y V] [V' W]^T reads them as two ld x 2nb operands
+    double *P = nullptr, *YVW[2] = {nullptr, nullptr}, *VT[2] = {nullptr, nullptr};
+    double *S = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
     hipStream_t side = nullptr, main = nullptr;
     hipEvent_t entry = nullptr;
     hipEvent_t panel_done[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> gemm_ev;        // per panel: (start, stop) of the critical and of the side updates
     std::vector<hipEvent_t> sample_ev;      // pairs (start, stop) around sampled gemv launches
     std::vector<double> sample_bytes;
 
     void release() {
-        double **ptrs[] = {&P, &V[0], &V[1], &Y, &VT[0], &VT[1], &W, &W2, &ypart, &acc, &scal};
+        double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = nbmax = 0; ysplits = 0;
     }
@@ -443,9 +446,9 @@ struct HessWorkspace {
             SN_HIP_CHECK(hipMalloc((void **)p, bytes));
             SN_HIP_CHECK(hipMemset(*p, 0, bytes));
         };
-        alloc(&P, pan); alloc(&V[0], pan); alloc(&V[1], pan); alloc(&Y, pan);
+        alloc(&P, pan); alloc(&YVW[0], 3 * pan); alloc(&YVW[1], 3 * pan);
         alloc(&VT[0], pan); alloc(&VT[1], pan);
-        alloc(&W, pan); alloc(&W2, pan);
+        alloc(&S, (size_t)nbmax * nbmax * sizeof(double)); alloc(&W2, pan);
         // one slice per column split of the gemv; the sharded path uses one per owned block column
         ysplits = need_splits;
         alloc(&ypart, (size_t)ysplits * ldp * sizeof(double));
@@ -494,10 +497,11 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
     ws.ensure(n, panel_width);
     int const ldp = ws.ldp;
     bool const aligned = (ldA % 2 == 0) && (((uintptr_t)dA) % 16 == 0);
-    double gemv_bytes = 0.0, gemm_flops = 0.0;
+    double gemv_bytes = 0.0, gemm_flops = 0.0, gemm_flops_main = 0.0;
     long gemv_launches = 0;
     size_t nsampled = 0;
     int const sample_every = tm ? tm->sample_every : 0;
+    bool const timed = tm != nullptr;
     ws.sample_bytes.clear();
 
     // everything runs on the library's own streams, fenced against the caller's stream
@@ -513,10 +517,10 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         int const nb = std::min(panel_width, end - i - 1);
         int const R0 = i + 1, E = end, m = E - R0;
         int const buf = pcount & 1;
-        double *V = ws.V[buf], *VT = ws.VT[buf];
+        double *Y = ws.YVW[buf], *V = Y + (size_t)ldp * nb, *W = V + (size_t)ldp * nb, *VT = ws.VT[buf];
         int const nwg = divceil(m, RB);
 
-        // V/VT of this slot were last used by the side stream two panels ago
+        // the buffers of this slot were last used by the side stream two panels ago
         if (pcount >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.side_done[buf], 0));
 
         SN_HIP_CHECK(hipMemsetAsync(ws.acc, 0, (size_t)ACC_TOTAL * sizeof(double), s));
@@ -528,7 +532,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             int const piv = R0 + j;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, ws.P, V, VT, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
+                    R0, E, j, ldp, ws.P, V, VT, Y, ws.ypart, nsplit, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, ws.P, V, ws.acc);
             int const ncols = E - piv;
@@ -568,17 +572,32 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             gemv_bytes += 8.0 * (double)m * (double)ncols;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
-            R0, E, nb, ldp, ws.P, V, ws.Y, ws.ypart, nsplit, ws.acc, ws.scal);
+            R0, E, nb, ldp, ws.P, V, Y, ws.ypart, nsplit, ws.acc, ws.scal);
 
-        // ---- critical trailing updates (core.c:523-547); VT = V*T comes from the panel ----
+        // ---- critical trailing updates (core.c:523-547), fused: with At the un-updated trailing
+        // block, V' = V(i+nb:, :) and VT = V*T from the panel,
+        //     W = (At - Y V'^T)^T VT = At^T VT - V' (Y^T VT)            (cpu.c:315-316, 373-384)
+        //     At <- At - Y V'^T - V W^T = At - [Y V] [V' W]^T            (cpu.c:315, 433-435)
+        // i.e. ONE read of At for W and ONE read-modify-write of At with k = 2 nb, instead of the
+        // reference's right update, left product and left update (three passes, two of them RMW).
+        if (timed) {
+            while (ws.gemm_ev.size() < 4 * (size_t)(pcount + 1)) {
+                hipEvent_t e; SN_HIP_CHECK(hipEventCreate(&e)); ws.gemm_ev.push_back(e);
+            }
+            SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 0], s));
+        }
         int const nt = E - (i + nb);
         if (nt > 0) {
             double *At = dA + (size_t)(i + nb) * ldA + R0;
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, ws.Y + R0, ldp, V + (i + nb), ldp, 1.0, At, ldA);
-            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, ws.W, ldp);
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, V + R0, ldp, ws.W, ldp, 1.0, At, ldA);
-            gemm_flops += 6.0 * m * (double)nt * nb;
+            double *Wt = W + (i + nb), *Vp = V + (i + nb);       // rows of W, V' <-> columns of At
+            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, Wt, ldp);
+            dgemm(s, 'T', 'N', nb, nb, m, 1.0, Y + R0, ldp, VT + R0, ldp, 0.0, ws.S, nb);
+            dgemm(s, 'N', 'N', nt, nb, nb, -1.0, Vp, ldp, ws.S, nb, 1.0, Wt, ldp);
+            dgemm(s, 'N', 'T', m, nt, 2 * nb, -1.0, Y + R0, ldp, Vp, ldp, 1.0, At, ldA);
+            double const f = 6.0 * m * (double)nt * nb + 2.0 * nb * (double)nb * (m + nt);
+            gemm_flops += f; gemm_flops_main += f;
         }
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 1], s));
         // panel columns go back into A (core.c:317)
         hipLaunchKernelGGL(hess_copy_out_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, ws.P, ldp);
@@ -587,6 +606,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         // ---- non-critical updates on the side stream (core.c:321-340) ----
         hipStream_t q = getenv("SN_HESS_NOSIDE") ? s : ws.side;
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)
             double *X = dA + (size_t)R0 * ldA;
             dgemm(q, 'N', 'N', R0, nb, m, 1.0, X, ldA, VT + R0, ldp, 0.0, ws.W2, ldp);
@@ -606,6 +626,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             dgemm(q, 'N', 'T', n, m, nb, -1.0, ws.W2, ldp, V + R0, ldp, 1.0, X, ldQ);
             gemm_flops += 4.0 * n * (double)m * nb;
         }
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 3], q));
         SN_HIP_CHECK(hipEventRecord(ws.side_done[buf], q));
     }
     // join the side stream back into s
@@ -620,6 +641,15 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         tm->total_ms = ms;
         tm->gemv_bytes = gemv_bytes;
         tm->gemm_flops = gemm_flops;
+        tm->gemm_flops_main = gemm_flops_main;
+        tm->gemm_ms_main = tm->gemm_ms_side = 0.0;
+        for (int p = 0; p < pcount; p++) {
+            float t = 0.f;
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[4 * p], ws.gemm_ev[4 * p + 1]));
+            tm->gemm_ms_main += t;
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[4 * p + 2], ws.gemm_ev[4 * p + 3]));
+            tm->gemm_ms_side += t;
+        }
         tm->gemv_launches = gemv_launches;
         tm->sampled_launches = (long)nsampled;
         tm->sampled_bytes = 0.0; tm->sampled_ms = 0.0;
@@ -630,7 +660,8 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             tm->sampled_bytes += ws.sample_bytes[k];
         }
     }
-    return 0;
+    // a reduction cut short by the profiling switch is not a result: tell the caller
+    return (max_panels < (1 << 30)) ? 1 : 0;
 }
 
 // ---- block-column sharded reduction over several GPUs (BASELINE config 4) -----
@@ -689,7 +720,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
 
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
     int pcount = 0;
-    double *V = ws.V[0], *VT = ws.VT[0];
+    double *Ys = ws.YVW[0], *V = Ys + (size_t)ldp * panel_width, *Ws = V + (size_t)ldp * panel_width, *VT = ws.VT[0];
     for (int i = begin; i < end - 1; i += panel_width, pcount++) {
         int const nb = std::min(panel_width, end - i - 1);
         int const R0 = i + 1, E = end, m = E - R0;
@@ -707,7 +738,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             int const piv = R0 + j;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, dP, V, VT, ws.Y, dYsum, 1, ws.acc, ws.scal);
+                    R0, E, j, ldp, dP, V, VT, Ys, dYsum, 1, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, dP, V, ws.acc);
             int const b0 = piv / cb;
@@ -733,7 +764,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             gemv_bytes += 8.0 * (double)m * (double)(E - piv) / world;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
-            R0, E, nb, ldp, dP, V, ws.Y, dYsum, 1, ws.acc, ws.scal);
+            R0, E, nb, ldp, dP, V, Ys, dYsum, 1, ws.acc, ws.scal);
 
         // trailing updates on the owned blocks right of the panel (core.c:523-547)
         for (int B = (i + nb) / cb; B * cb < E; B++) {
@@ -741,9 +772,9 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             int const c0 = std::max(B * cb, i + nb), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
             if (nt <= 0) continue;
             double *At = dA + (size_t)c0 * ldA + R0;
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, ws.Y + R0, ldp, V + c0, ldp, 1.0, At, ldA);
-            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, ws.W, ldp);
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, V + R0, ldp, ws.W, ldp, 1.0, At, ldA);
+            dgemm(s, 'N', 'T', m, nt, nb, -1.0, Ys + R0, ldp, V + c0, ldp, 1.0, At, ldA);
+            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, Ws, ldp);
+            dgemm(s, 'N', 'T', m, nt, nb, -1.0, V + R0, ldp, Ws, ldp, 1.0, At, ldA);
             gemm_flops += 6.0 * m * (double)nt * nb;
         }
         // every rank stores the finished panel columns (rows >= R0 are final)

@@ -37,6 +37,7 @@ namespace sn {
 
 void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
     double ident, double *acc);
+void sumsq_ordered(hipStream_t s, int m, int n, double const *X, int ldx, double *part, double *out);
 
 constexpr int WS_MAX = 96;          // diagonal window (rows) held in LDS
 constexpr int NB_MAX = 15;          // bulges per chain: 3*NB_MAX+1 <= WS_MAX/2 + ...
@@ -549,6 +550,7 @@ struct Driver {
         int col_split = 0;          // columns >= col_split are lazy for the steps being issued
     } sw;
     double sweep_flops = 0.0; int sweep_launches = 0;
+    int spw_cap = -1;           // conf->shifts_per_window (process_args.c:418-437)
     long chain_passes = 0;      // chains over all sweeps: the rounding error grows like its square root
     int lazy_batch = getenv("SN_SCHUR_LAZY_BATCH") ? atoi(getenv("SN_SCHUR_LAZY_BATCH")) : 32;
 
@@ -558,6 +560,7 @@ struct Driver {
         int nbulges = nshifts / 2;
         int ws_ = std::min(WS_MAX, size);
         int nbc = std::min(NB_MAX, (ws_ - 1) / 6);          // so that 2*(3 nbc) + 1 <= ws
+        if (spw_cap > 0) nbc = std::min(nbc, spw_cap / 2);  // conf->shifts_per_window
         if (nbc < 1) nbc = 1;
         if (size <= WS_MAX) nbc = std::min(nbulges, std::max(1, (size - 1) / 3));
         nbc = std::min(nbc, NB_MAX);
@@ -775,8 +778,8 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     double thres = prm.threshold;
     if (thres == -1.0 || thres == -2.0) {
         double h = 0.0;
-        SN_HIP_CHECK(hipMemsetAsync(ws.dAcc, 0, 8, s));
-        sumsq_diff(s, n, n, dH, ldH, nullptr, 0, 0.0, ws.dAcc);
+        // (fixed summation order: every replica of the reduction gets the same threshold bit for bit)
+        sumsq_ordered(s, n, n, dH, ldH, ws.dTmp, ws.dAcc);
         SN_HIP_CHECK(hipMemcpyAsync(&h, ws.dAcc, 8, hipMemcpyDeviceToHost, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
         thres = DBL_EPSILON * std::sqrt(h);
@@ -792,6 +795,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     std::vector<double> stale_r, stale_i;
     d.ts = s;
     d.nq = (q_rows >= 0) ? q_rows : n;
+    d.spw_cap = prm.shifts_per_window;
     auto replicate = [&](int nsh) {        // shift multiplicity (see `reuse` above)
         for (int r = 1; r < reuse; r++)
             for (int k = 0; k < nsh; k++) { sr[r * nsh + k] = sr[k]; si[r * nsh + k] = si[k]; }
@@ -843,6 +847,9 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
             ihi = ilo; continue;
         }
         if (size <= small_limit) {
+            // (a sweep head in flight above an open block: its bulges sit inside the rows this
+            // solve would touch and `ilo` is only the guard row -- let the sweep through first)
+            if (la && open_top) { finish_lookahead(ihi); continue; }
             if (ilo < ws.guard_row) d.set_guard_row(ilo);
             int info = d.small_block(ilo, size, real, imag);
             if (info != 0) { rc = STARNEIG_DID_NOT_CONVERGE; break; }

@@ -28,6 +28,7 @@ namespace sn {
 
 void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
     double ident, double *acc);
+void sumsq_ordered(hipStream_t s, int m, int n, double const *X, int ldx, double *part, double *out);
 
 constexpr int GWS = 64;             // diagonal window of the pencil held in LDS
 constexpr int GNB = 10;             // bulges per chain: 6*GNB + 1 <= GWS
@@ -612,8 +613,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     double thres = prm.threshold;
     if (thres == -1.0 || thres == -2.0) {
         double h = 0.0;
-        SN_HIP_CHECK(hipMemsetAsync(ws.dAcc, 0, 8, s));
-        sumsq_diff(s, n, n, dA, ldA, nullptr, 0, 0.0, ws.dAcc);
+        // (fixed summation order: every replica of the reduction gets the same threshold bit for bit)
+        sumsq_ordered(s, n, n, dA, ldA, ws.dTmp, ws.dAcc);
         SN_HIP_CHECK(hipMemcpyAsync(&h, ws.dAcc, 8, hipMemcpyDeviceToHost, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
         thres = DBL_EPSILON * std::sqrt(h);

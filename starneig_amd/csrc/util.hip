@@ -159,6 +159,49 @@ __global__ void count_below_kernel(int n, double const *__restrict__ H, int ldh,
     if (cnt != 0.0) atomicAdd(acc, cnt);
 }
 
+// Deterministic sum of squares (the deflation threshold u*||H||_F must be bit-identical on every
+// GPU that reduces a replica of H, and from run to run): per-block partial sums into `part`
+// (sumsq_ordered_parts(m, n) doubles), added up in a fixed order by one block.
+__global__ void sumsq_parts_kernel(int m, int n, double const *__restrict__ X, int ldx,
+    double *__restrict__ part)
+{
+    __shared__ double red[256];
+    int r = blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (r < m)
+        for (int c = blockIdx.y; c < n; c += gridDim.y) {
+            double v = X[(size_t)c * ldx + r];
+            s += v * v;
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void sum_ordered_kernel(int count, double const *__restrict__ part, double *out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+int sumsq_ordered_parts(int m, int n) { return divceil(m, 256) * std::min(n, 256); }
+void sumsq_ordered(hipStream_t s, int m, int n, double const *X, int ldx, double *part, double *out)
+{
+    dim3 grid(divceil(m, 256), std::min(n, 256));
+    hipLaunchKernelGGL(sumsq_parts_kernel, grid, dim3(256), 0, s, m, n, X, ldx, part);
+    hipLaunchKernelGGL(sum_ordered_kernel, dim3(1), dim3(256), 0, s, (int)(grid.x * grid.y), part, out);
+}
+
 void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
     double ident, double *acc)
 {

@@ -272,7 +272,7 @@ def hessenberg_device(tA, tQ, n=None, begin=0, end=None, panel_width=-1, stats=F
                       sample_every=0):
     n = tA.shape[0] if n is None else n
     end = n if end is None else end
-    st = (C.c_double * 8)() if stats else None
+    st = (C.c_double * 16)() if stats else None
     if stats:
         st[7] = float(sample_every)
     rc = load().starneig_amd_hessenberg_device(
@@ -281,7 +281,8 @@ def hessenberg_device(tA, tQ, n=None, begin=0, end=None, panel_width=-1, stats=F
     if stats:
         return rc, {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
                     "gemv_sampled_ms": st[3], "gemv_sampled_bytes": st[4],
-                    "gemv_launches": int(st[5]), "gemv_sampled_launches": int(st[6])}
+                    "gemv_launches": int(st[5]), "gemv_sampled_launches": int(st[6]),
+                    "gemm_main_ms": st[8], "gemm_main_flops": st[9], "gemm_side_ms": st[10]}
     return rc
 
 

@@ -29,7 +29,7 @@ def lcg_fullpos(n, seed=2019):
 
 
 def main():
-    for n in (64, 200, 512):
+    for n in (64, 200, 512, 2000):
         A = lcg_fullpos(n)
         H, Q = sl.hessenberg(A, calc_q=True)
         ev = np.linalg.eigvals(A)

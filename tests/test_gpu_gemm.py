@@ -21,6 +21,9 @@ SHAPES = [
     ("N", "T", 1000, 1000, 312),    # 128x128 tile path
     ("T", "N", 312, 300, 5001),     # split-K path (few output tiles, long k; beta = 0 only)
     ("T", "N", 40, 33, 2500),
+    ("N", "N", 700, 48, 2500),      # split-K, mn-contiguous row operand (W = Q (V T))
+    ("T", "N", 1500, 100, 4100),    # split-K with 128x64 tiles
+    ("N", "T", 700, 515, 624),      # fused trailing update shape (k = 2 nb), interior + edge tiles
 ]
 
 

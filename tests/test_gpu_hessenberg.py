@@ -59,7 +59,7 @@ def test_matches_oracle_default_conf(node, n):
         assert O.orthogonality_u(Q) < WARN_U
 
 
-@pytest.mark.parametrize("n", [64, 200, 512])
+@pytest.mark.parametrize("n", [64, 200, 512, 2000])
 def test_matches_lapack_golden(node, n):
     g = np.load(os.path.join(GOLDEN, f"hessenberg_lcg2019_n{n}.npz"))
     A0 = O.random_fullpos(n, seed=int(g["seed"]))

@@ -141,7 +141,7 @@ def test_full_chain_reduce_config1(node):
     assert abs(real.max() - np.abs(np.linalg.eigvals(A0[:n])).max()) <= 1e-10 * n
 
 
-@pytest.mark.parametrize("n", [64, 200, 512])
+@pytest.mark.parametrize("n", [64, 200, 512, 2000])
 def test_eigenvalues_match_lapack_golden(node, n):
     """committed numpy/LAPACK eigenvalues of the LCG matrices (tests/golden)"""
     import os

@@ -12,7 +12,7 @@ from helpers import U, WARN_U, elementwise_tolerance
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("n", [64, 200, 512])
+@pytest.mark.parametrize("n", [64, 200, 512, 2000])
 def test_oracle_matches_lapack_golden(n):
     g = np.load(os.path.join(GOLDEN, f"hessenberg_lcg2019_n{n}.npz"))
     A0 = O.random_fullpos(n, seed=int(g["seed"]))
@@ -102,7 +102,7 @@ def test_default_panel_width():
     assert [O.default_panel_width(n) for n in (2000, 4000, 8000, 20000)] == [280, 288, 288, 312]
 
 
-@pytest.mark.parametrize("n", [64, 200, 512])
+@pytest.mark.parametrize("n", [64, 200, 512, 2000])
 def test_schur_oracle_matches_lapack_golden_eigenvalues(n):
     """Schur leg of the oracle (double-shift QR restatement) against numpy/LAPACK eigenvalues of
     the same LCG matrix (fixture), plus the reference's Schur-form / residual checks."""
