@@ -59,9 +59,10 @@ constexpr int NG = 4;            // column groups (= waves) sharing one row in c
 constexpr int CT = 64 * NG;      // threads of colA / finish
 constexpr int NGC = 16;          // colC: its column loop is latency-bound, 16 groups cut it from 15 to 10 us
 constexpr int CTC = 64 * NGC;    // (colA gets slower with 16: 23 -> 36 us)
-constexpr int RBS = 16, NGS = 16; // rows / column groups of a shadow block inside the gemv launch
+constexpr int RBS = 32, NGS = 8;  // rows / column groups of a shadow block inside the gemv launch: with the
+                                  // ~5 streaming workgroups per CU they must all be resident at once (8 per CU)
 constexpr int GEMV_ROWS = 512;   // rows per workgroup of the big gemv (4 waves x 64 lanes x 2)
-constexpr int MAX_SPLIT = 32;
+constexpr int MAX_SPLIT = 64;
 constexpr int NSLOT = 8;         // atomic accumulator slots (spreads same-address contention)
 constexpr int MAXJ = 512;        // panel width limit of the column kernels
 
@@ -294,18 +295,18 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     __shared__ double s_wv[MAXJ], s_t[NGS][RBS + 1], s_scal[2];
     int const piv = R0 + j, par = j & 1;
     double const *__restrict__ pcol = P + (size_t)j * ldp;
-    if (threadIdx.x == 0) {
-        double scale, tau, beta;
-        reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
-        s_scal[0] = scale; s_scal[1] = tau;
-        if (blockIdx.x == 0) {   // published for colA(j+1) / finish
-            scal[4 * j + 0] = scale; scal[4 * j + 1] = tau; scal[4 * j + 2] = beta;
-        }
-    }
-    __syncthreads();
-    double const scale = s_scal[0];
 
     if ((int)blockIdx.x < nshadow) {
+        if (threadIdx.x == 0) {
+            double scale, tau, beta;
+            reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+            s_scal[0] = scale; s_scal[1] = tau;
+            if (blockIdx.x == 0) {   // published for colA(j+1) / finish
+                scal[4 * j + 0] = scale; scal[4 * j + 1] = tau; scal[4 * j + 2] = beta;
+            }
+        }
+        __syncthreads();
+        double const scale = s_scal[0];
         double const tau = s_scal[1];
         int const tid = threadIdx.x;
         int const r = tid & (RBS - 1), h = tid / RBS;
@@ -357,11 +358,23 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     }
     double *yp = ypart + (size_t)split * ldp;
     if (ALIGNED) {
-        int const g = (R0 & ~1) + tile * GEMV_ROWS + threadIdx.x * 2;
+        // row tiles start on a 128-byte line of A (tiles that straddle lines stream slower); the
+        // up to 15 rows above R0 are read and dropped
+        int const g = (R0 & ~15) + tile * GEMV_ROWS + threadIdx.x * 2;
         if (g >= E) return;
-        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        // y = A(:,piv) + scale * A(:,piv+1:) p''(piv+1:): the sum runs over the UNSCALED column (its
+        // entries are uniform values that feed the FMAs straight from scalar registers: 60 VGPRs,
+        // 8 waves per SIMD -- with the products scale*p'' held in vector registers it was 118 and the
+        // 5 workgroups per CU of the launch did not fit at once), and the reflector scalars are
+        // needed at the very end only, so no block waits for them before it starts to stream.
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, f0 = 0.0, f1 = 0.0;
         double const *a = A + (size_t)c_begin * ldA + g;
         int c = c_begin;
+        if (c == piv) {
+            d2 x = *reinterpret_cast<d2 const *>(a);
+            f0 = x.x; f1 = x.y;
+            c++; a += ldA;
+        }
         for (; c + UNROLL <= c_end; c += UNROLL) {
             d2 x[UNROLL];
             #pragma unroll
@@ -370,8 +383,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
                               : *reinterpret_cast<d2 const *>(a + (size_t)u * ldA);
             #pragma unroll
             for (int u = 0; u < UNROLL; u += 2) {
-                double v0 = (c + u == piv) ? 1.0 : scale * pcol[c + u];
-                double v1 = scale * pcol[c + u + 1];
+                double const v0 = pcol[c + u], v1 = pcol[c + u + 1];
                 a0 += x[u].x * v0;     a1 += x[u].y * v0;
                 b0 += x[u + 1].x * v1; b1 += x[u + 1].y * v1;
             }
@@ -379,22 +391,27 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
         }
         for (; c < c_end; c++) {
             d2 x = STREAM ? __builtin_nontemporal_load(reinterpret_cast<d2 const *>(a)) : *reinterpret_cast<d2 const *>(a);
-            double v0 = (c == piv) ? 1.0 : scale * pcol[c];
+            double const v0 = pcol[c];
             a0 += x.x * v0; a1 += x.y * v0;
             a += ldA;
         }
-        if (g >= R0) yp[g] = a0 + b0;
-        if (g + 1 < E) yp[g + 1] = a1 + b1;
+        double scale, tau, beta;
+        reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+        if (g >= R0) yp[g] = f0 + scale * (a0 + b0);
+        if (g + 1 >= R0 && g + 1 < E) yp[g + 1] = f1 + scale * (a1 + b1);
     } else {
         // odd leading dimension / unaligned base: 8-byte loads
         for (int q = 0; q < 2; q++) {
             int const g = R0 + tile * GEMV_ROWS + q * 256 + threadIdx.x;
             if (g >= E) continue;
-            double s = 0.0;
+            double s = 0.0, f = 0.0;
             double const *a = A + (size_t)c_begin * ldA + g;
-            for (int c = c_begin; c < c_end; c++, a += ldA)
-                s += (*a) * ((c == piv) ? 1.0 : scale * pcol[c]);
-            yp[g] = s;
+            int c = c_begin;
+            if (c == piv) { f = *a; c++; a += ldA; }
+            for (; c < c_end; c++, a += ldA) s += (*a) * pcol[c];
+            double scale, tau, beta;
+            reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+            yp[g] = f + scale * s;
         }
     }
 }
@@ -480,8 +497,13 @@ int hessenberg_panel_ld(int n, int) { return (int)roundup((size_t)n + GEMV_ROWS 
 static void choose_split(int m_rows, int ncols, int *nsplit, int *cps)
 {
     int row_tiles = divceil(m_rows + 1, GEMV_ROWS);
-    int want = std::max(1, 1280 / row_tiles);           // ~5 workgroups per CU (measured optimum)
-    int s = std::min({want, MAX_SPLIT, std::max(1, ncols / 16)});
+    // ~4 streaming workgroups per CU (measured at n = 20000: 4.70 / 4.71 / 4.80 / 4.9 s for 512 /
+    // 1024 / 1280 / 1792 workgroups); together with the shadow blocks of the launch they must all
+    // be resident at once (8 workgroups of 256 threads per CU at 64 VGPRs)
+    static int const target_wgs = getenv("SN_HESS_WGS") ? atoi(getenv("SN_HESS_WGS")) : 1024;
+    int want = std::max(1, target_wgs / row_tiles);
+    static int const max_split = getenv("SN_HESS_MAXSPLIT") ? atoi(getenv("SN_HESS_MAXSPLIT")) : 32;
+    int s = std::min({want, max_split, MAX_SPLIT, std::max(1, ncols / 16)});
     int c = divceil(ncols, s);
     c = (c + 15) / 16 * 16;
     s = divceil(ncols, c);
@@ -547,13 +569,23 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
                 }
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled], s));
             }
-            int const row_tiles = divceil(E - (R0 & ~1), GEMV_ROWS);
+            int const row_tiles = divceil(E - (R0 & ~15), GEMV_ROWS);
             int const nshadow = divceil(m, RBS);
             dim3 grid(nshadow + row_tiles * nsplit);
             // once the trailing matrix fits the 256 MB Infinity Cache the next column re-reads part of
             // it from there: temporal loads (the streaming, non-temporal ones bypass the caches).
             // Measured: 4 % on the whole reduction at n = 6000, nothing at n = 20000.
             static long const cache_bytes = (getenv("SN_HESS_CACHE_MB") ? atol(getenv("SN_HESS_CACHE_MB")) : 256L) << 20;
+            static int const exp_mode = getenv("SN_HESS_EXP") ? atoi(getenv("SN_HESS_EXP")) : 0;   // experiments
+            if (exp_mode == 3 && aligned) {     // no shadow work at all (WRONG results; timing only)
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(row_tiles * nsplit), dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, 0, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+            } else if (exp_mode == 2 && aligned) {     // shadow work as a launch of its own
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(nshadow), dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(row_tiles * nsplit), dim3(256), 0, s,
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, 0, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+            } else
             if (aligned && (long)m * ncols * 8 <= cache_bytes)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, false>), grid, dim3(256), 0, s,
                     dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
@@ -605,6 +637,8 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
 
         // ---- non-critical updates on the side stream (core.c:321-340) ----
         hipStream_t q = getenv("SN_HESS_NOSIDE") ? s : ws.side;
+        static bool const skip_side = getenv("SN_HESS_EXP") && atoi(getenv("SN_HESS_EXP")) == 1;  // timing experiment: WRONG results
+        if (skip_side) { SN_HIP_CHECK(hipEventRecord(ws.side_done[buf], q)); if (timed) { SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q)); SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 3], q)); } continue; }
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
         if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)
@@ -745,7 +779,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             int const first = b0 + ((rank - b0 % world) + world) % world;
             int const last_block = (E - 1) / cb;
             int nsplit = first > last_block ? 0 : (last_block - first) / world + 1;
-            int const row_tiles = divceil(E - (R0 & ~1), GEMV_ROWS);
+            int const row_tiles = divceil(E - (R0 & ~15), GEMV_ROWS);
             int const nshadow = divceil(m, RBS);
             if (nsplit > ws.ysplits) return -2;        // (cannot happen: one slice per block column)
             dim3 grid(nshadow + row_tiles * std::max(nsplit, 0));
