@@ -57,6 +57,49 @@ struct starneig_schur_conf {
 
 void starneig_schur_init_conf(struct starneig_schur_conf *conf);
 
+/* Eigenvalue reordering (reference expert.h:372-766).  Plans and blueprints name the reference's
+ * task-insertion strategies: valid values are accepted, there is one schedule here. */
+typedef enum {
+    STARNEIG_REORDER_DEFAULT_PLAN    = 1,
+    STARNEIG_REORDER_ONE_PART_PLAN   = 2,
+    STARNEIG_REORDER_MULTI_PART_PLAN = 3
+} starneig_reorder_plan_t;
+
+typedef enum {
+    STARNEIG_REORDER_DEFAULT_BLUEPRINT = 1,
+    STARNEIG_REORDER_DUMMY_INSERT_A = 2,
+    STARNEIG_REORDER_DUMMY_INSERT_B = 3,
+    STARNEIG_REORDER_CHAIN_INSERT_A = 4,
+    STARNEIG_REORDER_CHAIN_INSERT_B = 5,
+    STARNEIG_REORDER_CHAIN_INSERT_C = 6,
+    STARNEIG_REORDER_CHAIN_INSERT_D = 7,
+    STARNEIG_REORDER_CHAIN_INSERT_E = 8,
+    STARNEIG_REORDER_CHAIN_INSERT_F = 9
+} starneig_reorder_blueprint_t;
+
+#define STARNEIG_REORDER_DEFAULT_UPDATE_WIDTH               -1
+#define STARNEIG_REORDER_DEFAULT_UPDATE_HEIGHT              -1
+#define STARNEIG_REORDER_DEFAULT_TILE_SIZE                  -1
+#define STARNEIG_REORDER_DEFAULT_VALUES_PER_CHAIN           -1
+#define STARNEIG_REORDER_DEFAULT_WINDOW_SIZE                -1
+#define STARNEIG_REORDER_ROUNDED_WINDOW_SIZE                -2
+#define STARNEIG_REORDER_DEFAULT_SMALL_WINDOW_SIZE          -1
+#define STARNEIG_REORDER_DEFAULT_SMALL_WINDOW_THRESHOLD     -1
+
+struct starneig_reorder_conf {
+    starneig_reorder_plan_t plan;
+    starneig_reorder_blueprint_t blueprint;
+    int tile_size;
+    int values_per_chain;   /* rows of selected blocks that travel together (default: half a window) */
+    int window_size;        /* rows of a diagonal window, at most 128 here (default 128) */
+    int small_window_size;
+    int small_window_threshold;
+    int update_width;
+    int update_height;
+};
+
+void starneig_reorder_init_conf(struct starneig_reorder_conf *conf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,19 @@ starneig_error_t starneig_SEP_SM_Select(
 
 /* Hessenberg followed by Schur (the reordering leg of common/combined.c:46-98
  * is outside this path: predicate must be NULL). */
+/* reference sep_sm.h:174-179, :474-480 (reorder/interface.c:210-263): moves the selected
+ * eigenvalues (selected[i] != 0; a 2x2 block is selected as a whole) to the top-left corner of
+ * the Schur form, S <- U^T S U, Q <- Q U; on exit selected[] marks the final positions of the
+ * correctly placed eigenvalues.  Returns STARNEIG_PARTIAL_REORDERING when an exchange of two
+ * blocks was rejected as numerically unstable (the decomposition stays valid). */
+starneig_error_t starneig_SEP_SM_ReorderSchur(
+    int n, int selected[], double S[], int ldS, double Q[], int ldQ,
+    double real[], double imag[]);
+
+starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
+    struct starneig_reorder_conf *conf, int n, int selected[],
+    double S[], int ldS, double Q[], int ldQ, double real[], double imag[]);
+
 starneig_error_t starneig_SEP_SM_Reduce(
     int n, double A[], int ldA, double Q[], int ldQ,
     double real[], double imag[],

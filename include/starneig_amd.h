@@ -70,6 +70,16 @@ starneig_error_t starneig_amd_schur_rows_device(
     int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, double *real, double *imag,
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
+/* Eigenvalue reordering on a device-resident Schur form (replaces reorder/core.c + cpu.c /
+ * cuda.cu:126-761 + the GEMM updates of common/cpu.c:54-162): dS <- U^T dS U, dQ <- dQ U (dQ may
+ * be NULL).  selected is a HOST array (in: marks of the selected eigenvalues, out: final positions
+ * of the placed ones); real/imag HOST arrays (both NULL = not extracted).  conf may be NULL.
+ * stats (may be NULL) is double[2]: [0] windows processed, [1] executed GEMM flops. */
+struct starneig_reorder_conf;
+starneig_error_t starneig_amd_reorder_schur_device(
+    int n, int *selected, double *dS, int ldS, double *dQ, int ldQ, double *real, double *imag,
+    struct starneig_reorder_conf *conf, void *stream, double *stats);
+
 /* Generalized twin (BASELINE config 5): the device-resident Hessenberg-triangular pencil
  * (dH, dR) <- generalized real Schur form, dQ <- dQ*U1, dZ <- dZ*U2 (either may be NULL).
  * real/imag/beta are HOST arrays of length n (all NULL = not extracted).  Same conf and

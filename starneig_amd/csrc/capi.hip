@@ -18,6 +18,10 @@ void schur_release_workspace();
 void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double const *Y, int ldy,
     double ident, double *acc);
 void count_below(hipStream_t s, int n, double const *H, int ldh, double *acc);
+int reorder_schur_device(hipStream_t caller, int n, int *selected, double *dS, int ldS,
+    double *dQ, int ldQ, double *real, double *imag, int window_size, int values_per_chain,
+    double *stats);
+void reorder_release_workspace();
 }
 
 namespace {
@@ -110,6 +114,7 @@ SN_API void starneig_node_finalize(void)
     sn::hessenberg_release_workspace();
     sn::schur_release_workspace();
     sn::gep_schur_release_workspace();
+    sn::reorder_release_workspace();
     g_node.initialized = false;
 }
 
@@ -346,7 +351,113 @@ SN_API starneig_error_t starneig_SEP_SM_Select(
     return STARNEIG_SUCCESS;
 }
 
-// common/combined.c:46-98 without the reordering leg (predicate must be NULL)
+// reorder/interface.c:190-203
+SN_API void starneig_reorder_init_conf(struct starneig_reorder_conf *conf)
+{
+    conf->plan = STARNEIG_REORDER_DEFAULT_PLAN;
+    conf->blueprint = STARNEIG_REORDER_DEFAULT_BLUEPRINT;
+    conf->tile_size = STARNEIG_REORDER_DEFAULT_TILE_SIZE;
+    conf->window_size = STARNEIG_REORDER_DEFAULT_WINDOW_SIZE;
+    conf->values_per_chain = STARNEIG_REORDER_DEFAULT_VALUES_PER_CHAIN;
+    conf->small_window_size = STARNEIG_REORDER_DEFAULT_SMALL_WINDOW_SIZE;
+    conf->small_window_threshold = STARNEIG_REORDER_DEFAULT_SMALL_WINDOW_THRESHOLD;
+    conf->update_width = STARNEIG_REORDER_DEFAULT_UPDATE_WIDTH;
+    conf->update_height = STARNEIG_REORDER_DEFAULT_UPDATE_HEIGHT;
+}
+
+// reorder/core.c:470-651: plan / blueprint / window checks -> STARNEIG_INVALID_CONFIGURATION.
+// Plans and blueprints describe the reference's task-insertion strategies; there is one schedule
+// here, so valid values are accepted and have no effect.  window_size above 128 rows is clamped
+// (the in-place update tiles own a whole window); values_per_chain caps the rows of selected
+// blocks that travel together.
+static int reorder_params_from_conf(struct starneig_reorder_conf const *conf, int &window, int &vpc)
+{
+    window = -1; vpc = -1;
+    if (conf == NULL) return STARNEIG_SUCCESS;
+    if (conf->plan < STARNEIG_REORDER_DEFAULT_PLAN || conf->plan > STARNEIG_REORDER_MULTI_PART_PLAN)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->blueprint < STARNEIG_REORDER_DEFAULT_BLUEPRINT || conf->blueprint > STARNEIG_REORDER_CHAIN_INSERT_F)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->tile_size != STARNEIG_REORDER_DEFAULT_TILE_SIZE && conf->tile_size < 8)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->window_size != STARNEIG_REORDER_DEFAULT_WINDOW_SIZE &&
+        conf->window_size != STARNEIG_REORDER_ROUNDED_WINDOW_SIZE && conf->window_size < 4)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->values_per_chain != STARNEIG_REORDER_DEFAULT_VALUES_PER_CHAIN && conf->values_per_chain < 1)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->small_window_size != STARNEIG_REORDER_DEFAULT_SMALL_WINDOW_SIZE && conf->small_window_size < 4)
+        return STARNEIG_INVALID_CONFIGURATION;
+    if (conf->window_size > 0) window = conf->window_size;
+    if (conf->values_per_chain > 0) vpc = conf->values_per_chain;
+    return STARNEIG_SUCCESS;
+}
+
+SN_API starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
+    struct starneig_reorder_conf *conf, int n, int selected[],
+    double S[], int ldS, double Q[], int ldQ, double real[], double imag[])
+{
+    if (n < 1)              return -2;       // reorder/interface.c:213-218
+    if (selected == NULL)   return -3;
+    if (S == NULL)          return -4;
+    if (ldS < n)            return -5;
+    if (Q == NULL)          return -6;
+    if (ldQ < n)            return -7;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    int window, vpc;
+    int rc = reorder_params_from_conf(conf, window, vpc);
+    if (rc != STARNEIG_SUCCESS) return rc;
+
+    int const ld = (int)sn::roundup(n, 16);
+    size_t const bytes = (size_t)ld * n * sizeof(double);
+    double *dS = nullptr, *dQ = nullptr;
+    SN_HIP_CHECK(hipMalloc((void **)&dS, bytes));
+    SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+    SN_HIP_CHECK(hipMemset(dS, 0, bytes));
+    SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
+    SN_HIP_CHECK(hipMemcpy2D(dS, (size_t)ld * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
+    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
+    if (real == NULL || imag == NULL) real = imag = nullptr;
+    rc = sn::reorder_schur_device(nullptr, n, selected, dS, ld, dQ, ld, real, imag, window, vpc, nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+    SN_HIP_CHECK(hipMemcpy2D(S, (size_t)ldS * 8, dS, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipFree(dS));
+    SN_HIP_CHECK(hipFree(dQ));
+    return rc;
+}
+
+SN_API starneig_error_t starneig_SEP_SM_ReorderSchur(
+    int n, int selected[], double S[], int ldS, double Q[], int ldQ, double real[], double imag[])
+{
+    if (n < 1)              return -1;       // reorder/interface.c:244-249
+    if (selected == NULL)   return -2;
+    if (S == NULL)          return -3;
+    if (ldS < n)            return -4;
+    if (Q == NULL)          return -5;
+    if (ldQ < n)            return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    return starneig_SEP_SM_ReorderSchur_expert(NULL, n, selected, S, ldS, Q, ldQ, real, imag);
+}
+
+SN_API starneig_error_t starneig_amd_reorder_schur_device(
+    int n, int *selected, double *dS, int ldS, double *dQ, int ldQ, double *real, double *imag,
+    struct starneig_reorder_conf *conf, void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (selected == NULL)      return -2;
+    if (dS == NULL)            return -3;
+    if (ldS < n)               return -4;
+    if (dQ != NULL && ldQ < n) return -6;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    int window, vpc;
+    int rc = reorder_params_from_conf(conf, window, vpc);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    if (real == NULL || imag == NULL) real = imag = nullptr;
+    return sn::reorder_schur_device((hipStream_t)stream, n, selected, dS, ldS, dQ, ldQ, real, imag,
+        window, vpc, stats);
+}
+
+// common/combined.c:46-98
 SN_API starneig_error_t starneig_SEP_SM_Reduce(
     int n, double A[], int ldA, double Q[], int ldQ, double real[], double imag[],
     int (*predicate)(double real, double imag, void *arg), void *arg,
@@ -358,12 +469,18 @@ SN_API starneig_error_t starneig_SEP_SM_Reduce(
     if (Q == NULL)  return -4;
     if (ldQ < n)    return -5;           // common/combined.c:57-61: nothing beyond -5
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
-    if (predicate != NULL) return STARNEIG_GENERIC_ERROR;   // reordering is outside this path
-    (void)arg; (void)selected;
-    if (num_selected) *num_selected = 0;
     starneig_error_t rc = starneig_SEP_SM_Hessenberg(n, A, ldA, Q, ldQ);
     if (rc != STARNEIG_SUCCESS) return rc;
-    return starneig_SEP_SM_Schur(n, A, ldA, Q, ldQ, real, imag);
+    rc = starneig_SEP_SM_Schur(n, A, ldA, Q, ldQ, real, imag);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    if (predicate != NULL) {
+        std::vector<int> own;
+        if (selected == NULL) { own.resize(n); selected = own.data(); }
+        rc = starneig_SEP_SM_Select(n, A, ldA, predicate, arg, selected, num_selected);
+        if (rc != STARNEIG_SUCCESS) return rc;
+        rc = starneig_SEP_SM_ReorderSchur(n, selected, A, ldA, Q, ldQ, real, imag);
+    }
+    return rc;
 }
 
 // ---- generalized Schur (gep_sm.h) ---------------------------------------------

@@ -402,6 +402,40 @@ int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int t
     return here;
 }
 
+// ---- eigenvalue reordering inside one diagonal window (reorder/cpu.c reorder_window; LAPACK
+// dtrsen's loop of dtrexc calls) --------------------------------------------------------------
+// T (w x w, quasi-triangular) <- Z^T T Z with the selected diagonal blocks moved to the top of
+// the window, in their original order; Z accumulates from the right.  sel[i] != 0 marks the rows
+// of selected blocks (both rows of a 2x2 block carry the mark of the block: either one set
+// selects it).  On return sel holds the marks of the rows in their NEW order.  Returns the number
+// of rows of selected blocks now at the top; *failed is set when a swap was rejected (the blocks
+// involved are too close for a stable exchange): the blocks moved so far stay where they are, the
+// rejected one and everything selected below it keep their marks at their current rows.
+int reorder_window(int w, double *T, int ldt, double *Z, int ldz, int *sel, int *failed)
+{
+    *failed = 0;
+    int top = 0, i = 0;
+    while (i < w) {
+        int const bs = (i + 1 < w && T_(i + 1, i) != 0.0) ? 2 : 1;
+        bool const marked = sel[i] != 0 || (bs == 2 && sel[i + 1] != 0);
+        if (!marked) { i += bs; continue; }
+        if (i > top) {
+            int const at = move_block_up(w, T, ldt, Z, ldz, i, top);
+            // marks: rows [top, at) are unselected blocks that stayed above; the moved block sits
+            // at [at, at + bs); the rows it passed moved down by bs
+            for (int r = i + bs - 1; r >= at + bs; r--) sel[r] = 0;       // rows that moved down
+            for (int r = at; r < at + bs; r++) sel[r] = 1;
+            if (at != top) {                    // swap rejected on the way up
+                *failed = 1;
+                return top;
+            }
+        } else for (int r = i; r < i + bs; r++) sel[r] = 1;
+        top += bs;
+        i += bs;
+    }
+    return top;
+}
+
 // ---- shifts (schur/cpu_utils.c:3493-3594) ---------------------------------------------
 void extract_eigenvalues(int n, const double *T, int ldt, double *wr, double *wi)
 {
@@ -589,6 +623,9 @@ int sn_internal_small_schur(int n, double *T, int ldt, double *Z, int ldz, doubl
 __attribute__((visibility("default")))
 int sn_internal_move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
 { return sn::host::move_block_up(n, T, ldt, Z, ldz, from, to); }
+__attribute__((visibility("default")))
+int sn_internal_reorder_window(int w, double *T, int ldt, double *Z, int ldz, int *sel, int *failed)
+{ return sn::host::reorder_window(w, T, ldt, Z, ldz, sel, failed); }
 __attribute__((visibility("default")))
 int sn_internal_extract_shifts(int n, const double *T, int ldt, double *wr, double *wi)
 { return sn::host::extract_shifts(n, T, ldt, wr, wi); }

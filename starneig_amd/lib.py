@@ -21,6 +21,7 @@ NOT_INITIALIZED = 2
 INVALID_CONFIGURATION = 3
 INVALID_ARGUMENTS = 4
 DID_NOT_CONVERGE = 6
+PARTIAL_REORDERING = 7
 
 USE_ALL = -1
 DEFAULT = 0x0
@@ -40,6 +41,12 @@ class SchurConf(C.Structure):
         "window_size", "shifts_per_window", "update_width", "update_height")] + [
         ("left_threshold", C.c_double), ("right_threshold", C.c_double),
         ("inf_threshold", C.c_double)]
+
+
+class ReorderConf(C.Structure):
+    _fields_ = [(k, C.c_int) for k in (
+        "plan", "blueprint", "tile_size", "values_per_chain", "window_size", "small_window_size",
+        "small_window_threshold", "update_width", "update_height")]
 
 
 _dp = C.POINTER(C.c_double)
@@ -67,6 +74,12 @@ SIGNATURES = {
     "starneig_SEP_SM_Reduce": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "starneig_SEP_SM_Select": (C.c_int, [C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "starneig_reorder_init_conf": (None, [C.POINTER(ReorderConf)]),
+    "starneig_SEP_SM_ReorderSchur": (C.c_int, [C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "starneig_SEP_SM_ReorderSchur_expert": (
+        C.c_int, [C.POINTER(ReorderConf), C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "starneig_amd_reorder_schur_device": (
+        C.c_int, [C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(ReorderConf), _vp, _dp]),
     "starneig_GEP_SM_Schur": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     "starneig_GEP_SM_Schur_expert": (
@@ -144,6 +157,10 @@ def hessenberg_init_conf():
 
 # ---- host-array interface ---------------------------------------------------------
 
+def _arr_ptr(a):
+    return None if a is None else a.ctypes.data
+
+
 def _host_ptr(a):
     if a is None:
         return None
@@ -184,10 +201,6 @@ def SEP_SM_Schur_expert(conf, n, H, ldH, Q, ldQ, real, imag):
         None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data)
 
 
-def _arr_ptr(a):
-    return None if a is None else a.ctypes.data
-
-
 def GEP_SM_Schur(n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta):
     """reference gep_sm.h:164-170; eigenvalues are (real + i imag) / beta."""
     return load().starneig_GEP_SM_Schur(
@@ -203,14 +216,41 @@ def GEP_SM_Schur_expert(conf, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, bet
         _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta))
 
 
-def SEP_SM_Reduce(n, A, ldA, Q, ldQ, real, imag):
-    """reference sep_sm.h (Reduce) without predicate/selection."""
-    return load().starneig_SEP_SM_Reduce(
-        n, _host_ptr(A), ldA, _host_ptr(Q), ldQ, real.ctypes.data, imag.ctypes.data,
-        None, None, None, None)
-
-
 PREDICATE_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_void_p)
+
+
+def SEP_SM_Reduce(n, A, ldA, Q, ldQ, real, imag, predicate=None):
+    """reference sep_sm.h:230-240 (common/combined.c:46-98): Hessenberg + Schur (+ Select and
+    ReorderSchur when a predicate(real, imag) -> bool is given).  Returns rc without a predicate,
+    (rc, selected, count) with one."""
+    if predicate is None:
+        return load().starneig_SEP_SM_Reduce(
+            n, _host_ptr(A), ldA, _host_ptr(Q), ldQ, real.ctypes.data, imag.ctypes.data,
+            None, None, None, None)
+    cb = PREDICATE_FN(lambda re, im, arg: 1 if predicate(re, im) else 0)
+    sel = np.zeros(n, dtype=np.int32)
+    cnt = C.c_int(0)
+    rc = load().starneig_SEP_SM_Reduce(
+        n, _host_ptr(A), ldA, _host_ptr(Q), ldQ, real.ctypes.data, imag.ctypes.data,
+        C.cast(cb, C.c_void_p), None, sel.ctypes.data, C.addressof(cnt))
+    return rc, sel, cnt.value
+
+
+def reorder_init_conf():
+    conf = ReorderConf()
+    load().starneig_reorder_init_conf(C.byref(conf))
+    return conf
+
+
+def SEP_SM_ReorderSchur(n, selected, S, ldS, Q, ldQ, real, imag, conf=None):
+    """reference sep_sm.h:174-179 / :474-480; selected: int32 array of length n (in/out)."""
+    assert selected.dtype == np.int32
+    if conf is None:
+        return load().starneig_SEP_SM_ReorderSchur(
+            n, selected.ctypes.data, _host_ptr(S), ldS, _host_ptr(Q), ldQ, _arr_ptr(real), _arr_ptr(imag))
+    return load().starneig_SEP_SM_ReorderSchur_expert(
+        C.byref(conf), n, selected.ctypes.data, _host_ptr(S), ldS, _host_ptr(Q), ldQ,
+        _arr_ptr(real), _arr_ptr(imag))
 
 
 def SEP_SM_Select(n, S, ldS, predicate):
@@ -300,6 +340,20 @@ def schur_device(tH, tQ, n=None, conf=None, eigenvalues=True):
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
              "aed_host_s": st[6], "gpu_wait_s": st[7]}
     return rc, real, imag, stats
+
+
+def reorder_schur_device(tS, tQ, selected, n=None, conf=None, eigenvalues=True):
+    """Returns (rc, real, imag, stats); `selected` (int32, length n) is updated in place."""
+    n = tS.shape[0] if n is None else n
+    assert selected.dtype == np.int32
+    real = np.zeros(n) if eigenvalues else None
+    imag = np.zeros(n) if eigenvalues else None
+    st = (C.c_double * 2)()
+    rc = load().starneig_amd_reorder_schur_device(
+        n, selected.ctypes.data, _dev_ptr(tS), tS.shape[1], _dev_ptr(tQ),
+        tQ.shape[1] if tQ is not None else 0, _arr_ptr(real), _arr_ptr(imag),
+        C.byref(conf) if conf is not None else None, _stream_ptr(), st)
+    return rc, real, imag, {"windows": int(st[0]), "gemm_flops": st[1]}
 
 
 def gep_schur_device(tH, tR, tQ, tZ, n=None, conf=None, eigenvalues=True):

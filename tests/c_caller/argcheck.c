@@ -96,6 +96,21 @@ int main(void)
     EXPECT(starneig_SEP_SM_Select(n, A, ld, always, NULL, NULL, &cnt), -6);
     EXPECT(starneig_SEP_SM_Select(n, A, ld, always, NULL, sel, &cnt), STARNEIG_NOT_INITIALIZED);
 
+    /* reorder/interface.c:213-218, :244-249 */
+    EXPECT(starneig_SEP_SM_ReorderSchur(0, sel, A, ld, Q, ld, re, im), -1);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, NULL, A, ld, Q, ld, re, im), -2);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, sel, NULL, ld, Q, ld, re, im), -3);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, sel, A, n - 1, Q, ld, re, im), -4);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, sel, A, ld, NULL, ld, re, im), -5);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, sel, A, ld, Q, n - 1, re, im), -6);
+    EXPECT(starneig_SEP_SM_ReorderSchur(n, sel, A, ld, Q, ld, re, im), STARNEIG_NOT_INITIALIZED);
+    struct starneig_reorder_conf rc_;
+    starneig_reorder_init_conf(&rc_);
+    EXPECT(rc_.plan, STARNEIG_REORDER_DEFAULT_PLAN);
+    EXPECT(rc_.window_size, STARNEIG_REORDER_DEFAULT_WINDOW_SIZE);
+    EXPECT(starneig_SEP_SM_ReorderSchur_expert(&rc_, 0, sel, A, ld, Q, ld, re, im), -2);
+    EXPECT(starneig_SEP_SM_ReorderSchur_expert(&rc_, n, sel, A, ld, Q, n - 1, re, im), -7);
+
     free(A); free(Q); free(B); free(Z);
     if (failures == 0) printf("argcheck ok\n");
     return failures ? 1 : 0;

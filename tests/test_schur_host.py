@@ -119,3 +119,38 @@ def test_aed_window_invariants(nw, sub_scale):
     assert abs(abs(spike[0]) - np.linalg.norm(full[:ns])) <= 100 * U * abs(sub)
     assert np.all(np.abs(full[ns:]) < thres)
     assert nshift <= nw
+
+
+@pytest.mark.parametrize("n,seed", [(12, 1), (60, 2), (128, 3)])
+def test_reorder_window_moves_selected_blocks_to_the_top(n, seed):
+    """host::reorder_window (the window kernel of starneig_SEP_SM_ReorderSchur; reference
+    reorder/cpu.c, LAPACK dtrsen semantics): selected blocks at the top in their original order,
+    similarity and orthogonality preserved, marks follow the rows, against scipy's sorted Schur."""
+    L = S.lib.load()
+    ip = C.POINTER(C.c_int)
+    L.sn_internal_reorder_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, ip, ip]
+    H0 = hess_input(n, seed=seed)
+    T = H0.copy(order="F"); Z = np.asfortranarray(np.eye(n))
+    wr = np.zeros(n); wi = np.zeros(n)
+    assert lib().sn_internal_small_schur(n, P(T), n, P(Z), n, P(wr), P(wi)) == 0
+    T0 = T.copy(order="F")
+    sel = (wr > np.median(wr)).astype(np.int32)
+    # one mark of a pair is enough to select the block
+    for i in range(n - 1):
+        if T[i + 1, i] != 0.0 and sel[i]:
+            sel[i + 1] = 0
+    want = [(wr[i], wi[i]) for i in range(n) if wr[i] > np.median(wr)]
+    Zw = np.asfortranarray(np.eye(n)); failed = C.c_int(0)
+    placed = L.sn_internal_reorder_window(n, P(T), n, P(Zw), n, sel.ctypes.data_as(ip), C.byref(failed))
+    assert failed.value == 0 and placed == len(want)
+    assert is_quasi_triangular(T)
+    assert np.linalg.norm(Zw @ T @ Zw.T - T0) <= 500 * U * np.linalg.norm(T0)
+    assert np.linalg.norm(Zw @ Zw.T - np.eye(n)) <= 200 * U * np.sqrt(n)
+    assert np.array_equal(sel, (np.arange(n) < placed).astype(np.int32))
+    er, ei = O.extract_eigenvalues(np.asfortranarray(T))
+    # the selected eigenvalues, in their original order, now lead the diagonal
+    got = np.array(er[:placed]) + 1j * np.array(ei[:placed])
+    exp = np.array([a for a, b in want]) + 1j * np.array([b for a, b in want])
+    assert np.abs(got - exp).max() <= 1e5 * U * np.abs(exp).max()
+    # and nothing selected is left below
+    assert np.all(np.array(er[placed:]) <= np.median(wr) + 1e5 * U * np.abs(wr).max())
