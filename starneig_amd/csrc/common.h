@@ -104,6 +104,7 @@ struct SchurStats {
     float total_ms = 0.f;
     double aed_host_s = 0.0;    // wall time inside the host AED kernel
     double wait_s = 0.0;        // wall time the host waited for the GPU (window downloads)
+    int inf_deflated = 0;       // pencils: infinite eigenvalues chased out and deflated
 };
 // Reduces the device-resident upper Hessenberg matrix dH to real Schur form, dQ <- dQ*U.
 // real/imag are HOST arrays (may be NULL).  Returns a starneig_error_t value.

@@ -9,9 +9,11 @@
 // pencil held in LDS together with BOTH accumulated orthogonal factors (4 x 64 x 65 doubles =
 // 133 KB of the 160 KB LDS); all off-diagonal updates are in-place fp64-MFMA GEMMs on a
 // near/far stream pair.  AED windows and small blocks are reduced on the host
-// (schur_host_gep.hip).  Not rebuilt in this revision: the reference's infinite-eigenvalue
-// deflation (push_inf_*, cpu_utils.c:360-799) -- a numerically singular B is treated as a
-// perturbation of size u*||B||_F.
+// (schur_host_gep.hip).  Infinite eigenvalues (push_inf_*, cpu_utils.c:360-799,
+// core.c:475-552): before a block is worked on, every diagonal entry of B below the infinity
+// threshold (u*||B||_F by default) is chased to the top of the block through a chain of <= 128-row
+// windows on pinned host copies -- the rotations of a window reach the rest of A, B, Q, Z as
+// in-place MFMA GEMMs -- and deflated there with beta = 0 exactly (GepDriver::push_infinite).
 #include "common.h"
 #include "schur_host.h"
 #include "dgemm_tile.h"
@@ -243,10 +245,14 @@ void gep_update_kernel(SweepStep const step, double *__restrict__ A, int ldA,
 }
 
 // sub[i] = A(i+1,i) for i in [0,hi-1); entries below the threshold become exact zeros
+// bflag[i] = 1 where |B(i,i)| is below the infinity threshold (schur/core.c:475-552 scans the
+// same way before it inserts its push_inf tasks)
 __global__ void gep_scan_subdiag_kernel(int hi, double *__restrict__ A, int ldA, double thres,
-    double *__restrict__ sub)
+    double *__restrict__ sub, double const *__restrict__ B, int ldB, double thres_inf,
+    double *__restrict__ bflag)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < hi) bflag[i] = (fabs(B[(size_t)i * ldB + i]) < thres_inf) ? 1.0 : 0.0;
     if (i >= hi - 1) return;
     double *p = A + (size_t)i * ldA + i + 1;
     double v = *p;
@@ -303,7 +309,7 @@ struct GepWorkspace {
         SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)n * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dSub, (size_t)2 * n * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dQl, w2));
         SN_HIP_CHECK(hipMalloc((void **)&dZl, w2));
         SN_HIP_CHECK(hipMalloc((void **)&dTmp, (size_t)n * nwmax * 8));
@@ -312,7 +318,7 @@ struct GepWorkspace {
         SN_HIP_CHECK(hipHostMalloc((void **)&hB, w2, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hQ, w2, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hZ, w2, hipHostMallocDefault));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)2 * n * 8, hipHostMallocDefault));
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)gep_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, GEP_CHASE_LDS_BYTES));
@@ -453,6 +459,48 @@ struct GepDriver {
         if (real) for (int i = 0; i < w; i++) { real[lo + i] = ar[i]; imag[lo + i] = ai[i]; beta[lo + i] = be[i]; }
         st.small_solves++;
         return 0;
+    }
+
+    // Infinite eigenvalues of the active block [ilo, ihi): every diagonal entry of B below the
+    // threshold is chased to the top of the block -- window by window on pinned host copies
+    // (host::gep_push_inf_window), the rows and columns outside a window see the accumulated
+    // rotations through the usual GEMM updates -- and deflated there: A(to+1,to) = 0, B(to,to) = 0
+    // exactly, eigenvalue (A(to,to), 0).  Returns the number of deflated eigenvalues.
+    int push_infinite(int ilo, int ihi, double thres_inf, double *real, double *imag, double *beta)
+    {
+        int const W = std::min(128, ws.nwmax);
+        int to = ilo, count = 0;
+        std::vector<double> dg(ihi - ilo);
+        while (to + 1 < ihi) {
+            int const len = ihi - to;
+            SN_HIP_CHECK(hipMemcpy2DAsync(dg.data(), 8, B + (size_t)to * ldB + to, (size_t)(ldB + 1) * 8, 8, len,
+                hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            int z = -1;
+            for (int i = 0; i < len; i++) if (std::fabs(dg[i]) < thres_inf) { z = to + i; break; }
+            if (z < 0) break;
+            int cur = z;
+            double alpha = 0.0;
+            for (;;) {
+                int const we = std::min(ihi, cur + 2), wb = std::max(to, we - W), w = we - wb;
+                int const ldh = host_ld(w);
+                download_windows(wb, w);
+                for (int j = 0; j < w; j++)
+                    for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
+                bool const last = (wb == to);
+                host::gep_push_inf_window(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, cur - wb, 0, last ? 1 : 0);
+                if (last) alpha = ws.hA[0];
+                upload_windows(wb, w);
+                apply_transform(wb, w, ws.dQl, ws.dZl, w);
+                SN_HIP_CHECK(hipStreamSynchronize(s));
+                cur = wb;
+                if (last) break;
+            }
+            if (real) { real[to] = alpha; imag[to] = 0.0; beta[to] = 0.0; }
+            to++; count++;
+        }
+        st.inf_deflated += count;
+        return count;
     }
 
     // Q and Z updates of the window steps: issued after the sweep's critical path, on the lazy
@@ -621,21 +669,44 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     } else if (thres == -3.0) thres = 0.0;
     else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
 
+    // infinity threshold: u*||B||_F by default (schur/core.c:2440-2470)
+    double thres_inf = prm.threshold_inf;
+    if (thres_inf == -1.0 || thres_inf == -2.0) {
+        double h = 0.0;
+        sumsq_ordered(s, n, n, dB, ldB, ws.dTmp, ws.dAcc);
+        SN_HIP_CHECK(hipMemcpyAsync(&h, ws.dAcc, 8, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        thres_inf = DBL_EPSILON * std::sqrt(h);
+    } else if (thres_inf <= 0.0) return STARNEIG_INVALID_CONFIGURATION;
+
     std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
     int rc = STARNEIG_SUCCESS;
     int ihi = n, iter = 0, stagnation = 0;
     while (ihi > 0) {
-        hipLaunchKernelGGL(gep_scan_subdiag_kernel, dim3(divceil(std::max(ihi - 1, 1), 256)), dim3(256),
-            0, s, ihi, dA, ldA, thres, ws.dSub);
-        if (ihi > 1) {
+        hipLaunchKernelGGL(gep_scan_subdiag_kernel, dim3(divceil(ihi, 256)), dim3(256),
+            0, s, ihi, dA, ldA, thres, ws.dSub, dB, ldB, thres_inf, ws.dSub + n);
+        {
             double tw = wall();
-            SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
+            if (ihi > 1)
+                SN_HIP_CHECK(hipMemcpyAsync(ws.hSub, ws.dSub, (size_t)(ihi - 1) * 8, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipMemcpyAsync(ws.hSub + n, ws.dSub + n, (size_t)ihi * 8, hipMemcpyDeviceToHost, s));
             SN_HIP_CHECK(hipStreamSynchronize(s));
             d.st.wait_s += wall() - tw;
         }
         int ilo = ihi - 1;
         while (ilo > 0 && ws.hSub[ilo - 1] != 0.0) ilo--;
         int const size = ihi - ilo;
+        // ---- infinite eigenvalues: zeros on B's diagonal inside the active block are chased to its
+        // top and deflated (schur/core.c:475-552, cpu_utils.c:360-425, :605-681)
+        if (size >= 2) {
+            bool any = false;
+            for (int i = ilo; i < ihi && !any; i++) any = ws.hSub[n + i] != 0.0;
+            if (any) {
+                d.push_infinite(ilo, ihi, thres_inf, real, imag, beta);
+                stagnation = 0;
+                continue;
+            }
+        }
         if (size <= small_limit) {
             int info = d.small_block(ilo, size, real, imag, beta);
             if (info != 0) { rc = STARNEIG_DID_NOT_CONVERGE; break; }

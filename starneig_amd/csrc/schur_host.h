@@ -22,6 +22,8 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
 // ---- generalized problem (schur_host_gep.hip) ---------------------------------------------
 void gep_extract_eigenvalues(int n, const double *S, int lds, const double *T, int ldt,
     double *ar, double *ai, double *be);
+void gep_push_inf_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int from, int to, int deflate);
 int gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int nq, double *ar, double *ai, double *be);
 void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,

@@ -8,10 +8,12 @@
 // here: the published algorithms (Moler & Stewart's QZ step as in Golub & Van Loan
 // Alg. 7.7.2, the dgghrd Givens scheme) are written out for windows of a few hundred rows.
 // Differences to LAPACK's dhgeqz: always the implicit double-shift step (real shift pairs
-// included); a (numerically) zero diagonal entry of B inside an active block is perturbed to
-// u*||B||_F instead of being chased out as an infinite eigenvalue (a backward error of the
-// same size as rounding; the reference's push_inf_* machinery, cpu_utils.c:360-799, is not
-// rebuilt).  Reordering inside the AED window swaps adjacent blocks through the generalized
+// included).  Infinite eigenvalues: a diagonal entry of B below the infinity threshold inside an
+// active block is chased to the top of the block and deflated there (gep_push_inf_window: the
+// rotation scheme of the reference's push_inf_up, schur/cpu_utils.c:360-425, driven window by
+// window from schur_gep.hip); the small-pencil kernels below only guard against entries that
+// turn up mid-iteration (perturbation to u*||B||_F, a backward error of the size of rounding).
+// Reordering inside the AED window swaps adjacent blocks through the generalized
 // Sylvester equation like LAPACK dtgex2.
 #include "schur_host.h"
 #include <cmath>
@@ -188,6 +190,46 @@ static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
 
 // Eigenvalues (alpha_r + i alpha_i) / beta of a generalized Schur form (S quasi-triangular,
 // T upper triangular with standardised 2x2 blocks) -- reference common/math.c:148-176 (dlag2).
+// Infinite-eigenvalue chase inside one window (schur/cpu_utils.c:360-425, push_inf_up): B is
+// upper triangular with B(from,from) (numerically) zero, A upper Hessenberg.  A column
+// rotation moves the zero one position up the diagonal, a row rotation removes the fill it
+// leaves below A's sub-diagonal; after from-to steps the zero sits at B(to,to).  With
+// deflate != 0 (to is the first row of the active block) a last row rotation annihilates
+// A(to+1,to): the pencil splits off the 1x1 block (A(to,to), 0) -- an infinite eigenvalue.
+// Q, Z (w x w) accumulate the row / column rotations from the right.  The zero may sit in the
+// last row of the window only when that row is the last row of the active block (no fill).
+void gep_push_inf_window(int w, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
+    double *Z_, int ldz, int from, int to, int deflate)
+{
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    for (int i = from; i > to; i--) {
+        double const x = B(i - 1, i - 1), y = B(i - 1, i), r = std::hypot(x, y);
+        double c = 1.0, s = 0.0;
+        if (r != 0.0) { c = y / r; s = -x / r; }         // [x y] G = [0 r]
+        rot_cols(A, i - 1, i, 0, std::min(w, i + 2), c, s);
+        rot_cols(B, i - 1, i, 0, i - 1, c, s);
+        rot_cols(Z, i - 1, i, 0, w, c, s);
+        B(i - 1, i) = r; B(i - 1, i - 1) = 0.0;
+        if (i + 1 < w) {
+            double c2, s2, r2;
+            givens(A(i, i - 1), A(i + 1, i - 1), c2, s2, r2);
+            rot_rows(A, i, i + 1, i, w, c2, s2);
+            rot_rows(B, i, i + 1, i + 1, w, c2, s2);
+            rot_cols(Q, i, i + 1, 0, w, c2, s2);
+            A(i, i - 1) = r2; A(i + 1, i - 1) = 0.0;
+        }
+    }
+    if (deflate && to + 1 < w) {
+        double c2, s2, r2;
+        givens(A(to, to), A(to + 1, to), c2, s2, r2);
+        rot_rows(A, to, to + 1, to + 1, w, c2, s2);
+        rot_rows(B, to, to + 1, to + 1, w, c2, s2);
+        rot_cols(Q, to, to + 1, 0, w, c2, s2);
+        A(to, to) = r2; A(to + 1, to) = 0.0;
+        B(to, to) = 0.0;
+    }
+}
+
 void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_, int ldt,
     double *ar, double *ai, double *be)
 {
@@ -619,6 +661,10 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
 
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
+__attribute__((visibility("default")))
+void sn_internal_gep_push_inf_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int from, int to, int deflate)
+{ sn::host::gep_push_inf_window(w, A, lda, B, ldb, Q, ldq, Z, ldz, from, to, deflate); }
 __attribute__((visibility("default")))
 int sn_internal_gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, double *ar, double *ai, double *be)

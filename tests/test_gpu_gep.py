@@ -213,3 +213,67 @@ def test_qz_device_without_q_and_z(node):
         else:
             assert torch.equal(ref[0], tH) and torch.equal(ref[1], tR)
             assert np.array_equal(ref[2], ar) and np.array_equal(ref[4], be)
+
+
+@pytest.mark.parametrize("n,zeros", [(40, [7]), (300, [0, 5, 100, 101, 299]), (700, [350, 351, 352, 698])])
+def test_qz_infinite_eigenvalues_are_deflated(node, n, zeros):
+    """Row S9: exact zeros on the diagonal of B (singular B) -- the infinite eigenvalues are chased
+    to the top of their block and deflated with beta = 0 (schur/cpu_utils.c:360-425, :605-681,
+    schur/core.c:475-552), not perturbed away; the finite ones agree with LAPACK's QZ."""
+    import scipy.linalg as sl
+    H0, R0 = O.random_pencil_wellcond(n)
+    for k in zeros:
+        R0[k, k] = 0.0
+    H, R, Q, Z, ar, ai, be = run_host(node, H0, R0)
+    assert O.check_gep_schur_form(H, R) == 0
+    assert O.pencil_residual_u(Q, H, Z, H0) < WARN_U and O.pencil_residual_u(Q, R, Z, R0) < WARN_U
+    assert O.orthogonality_u(Q) < WARN_U and O.orthogonality_u(Z) < WARN_U
+    inf = be == 0.0
+    # (consecutive zeros on B's diagonal share infinite eigenvalues: [[0, b], [0, 0]] has rank 1 --
+    # the count is LAPACK's on the same pencil: 1, 4 and 3 for the three cases)
+    w = sl.eig(H0[:n], R0[:n], right=False, homogeneous_eigvals=True)
+    n_inf = int((np.abs(w[1]) < 1e-10 * np.abs(w[0])).sum())
+    assert 1 <= n_inf <= len(zeros)
+    assert int(inf.sum()) == n_inf, (int(inf.sum()), n_inf, np.sort(np.abs(be))[:8])
+    # an infinite eigenvalue is a 1x1 block with T(i,i) exactly zero and a real alpha != 0
+    for i in np.nonzero(inf)[0]:
+        assert R[i, i] == 0.0 and ai[i] == 0.0 and ar[i] == H[i, i] and ar[i] != 0.0
+        assert (i + 1 >= n or H[i + 1, i] == 0.0) and (i == 0 or H[i, i - 1] == 0.0)
+    # finite eigenvalues against LAPACK (scipy.linalg.eig on the pencil, homogeneous form)
+    fin = np.abs(w[1]) >= 1e-10 * np.abs(w[0])
+    fin_ref = w[0][fin] / w[1][fin]
+    lam = (ar[~inf] + 1j * ai[~inf]) / be[~inf]
+    assert lam.size == fin_ref.size
+    # forward comparison where the infinite eigenvalues are simple; a shared (defective) infinite
+    # eigenvalue makes its finite neighbours ill-conditioned (1e-6 relative between LAPACK and any
+    # other backward-stable QZ) -- there the conditioning-independent check decides: every
+    # returned pair is an exact eigenvalue of a pencil within 500 u of the input
+    if all(b - a > 1 for a, b in zip(zeros, zeros[1:])):
+        assert O.match_eigenvalues(lam, fin_ref) < 1e7
+    assert eig_backward_error_u(H0, R0, ar + 1j * ai, be, sample=32) < WARN_U
+
+
+def test_qz_infinite_eigenvalues_device_n3000(node):
+    """the same on a device-resident pencil with 1 % of B's diagonal zeroed"""
+    import torch
+    n = 3000
+    H0, R0 = O.random_pencil_wellcond(n)
+    zeros = list(range(17, n, 100))
+    for k in zeros:
+        R0[k, k] = 0.0
+    tH, tR = to_device(H0), to_device(R0)
+    tH0, tR0 = tH.clone(), tR.clone()
+    tQ, tZ = node.device_matrix(n, ld=H0.shape[0]), node.device_matrix(n, ld=H0.shape[0])
+    node.set_matrix_device(tQ, n, n, 0.0, 1.0); node.set_matrix_device(tZ, n, n, 0.0, 1.0)
+    rc, ar, ai, be, st = node.gep_schur_device(tH, tR, tQ, tZ, n=n)
+    torch.cuda.synchronize()
+    assert rc == 0
+    rc, ca = node.check_pencil_device(tQ, tH, tZ, tH0, n=n)
+    assert rc == 0
+    rc, cb = node.check_pencil_device(tQ, tR, tZ, tR0, n=n)
+    assert rc == 0
+    assert ca["residual_u"] < WARN_U and cb["residual_u"] < WARN_U
+    assert ca["orthogonality_q_u"] < WARN_U and ca["orthogonality_z_u"] < WARN_U
+    assert ca["below_subdiagonal"] == 0 and cb["below_subdiagonal"] == 0
+    assert int((be == 0.0).sum()) == len(zeros)
+    assert O.check_gep_schur_form(to_host(tH), to_host(tR)) == 0
