@@ -111,7 +111,8 @@ struct SchurStats {
 // q_rows >= 0: dQ points at a block of q_rows rows of Q and only those are updated (row-sharded
 // accumulation of Q over several GPUs that each reduce a replica of H).
 int schur_device(hipStream_t s, int n, double *dH, int ldH, double *dQ, int ldQ,
-    double *real, double *imag, SchurParams const &params, SchurStats *stats, int q_rows = -1);
+    double *real, double *imag, SchurParams const &params, SchurStats *stats, int q_rows = -1,
+    int level = 0);
 void schur_release_workspace();
 // Generalized twin (schur_gep.hip): (dA, dB) Hessenberg-triangular -> generalized Schur form
 int gep_schur_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,

@@ -98,6 +98,23 @@ __device__ __forceinline__ double nrm_sum(double const *__restrict__ acc, int pa
     return s;
 }
 
+// y(g) = sum over the column splits of the gemv partials: 8 independent loads in flight (the
+// plain loop waits for one L2 round trip per split -- 32 of them on the column chain)
+__device__ __forceinline__ double split_sum(double const *__restrict__ ypart, int ldp, int g, int nsplit)
+{
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        double x[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = ypart[(size_t)(s + q) * ldp + g];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) a[q] += x[q];
+    }
+    for (; s < nsplit; s++) a[0] += ypart[(size_t)s * ldp + g];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 // In-block transposed gemv: out[l] += sum_{r<RB} M[g0+r, l] * sp[r], l < ncols.
 // CT threads = 16 row lanes x CT/16 column groups; 16 lanes read 128 contiguous
 // bytes of one column, the 16-lane DPP row reduces them, one atomic per column.
@@ -106,10 +123,30 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
     int g0, int ncols, double const *sp, double *__restrict__ out)
 {
     int const rsub = threadIdx.x & 15, csub = threadIdx.x >> 4;
+    constexpr int CG = THREADS / 16;
     double pr[RB / 16];
     #pragma unroll
     for (int it = 0; it < RB / 16; it++) pr[it] = sp[it * 16 + rsub];
-    for (int l = csub; l < ncols; l += THREADS / 16) {
+    // four columns per trip: 16 independent loads in flight per lane (the loop is latency-bound)
+    int l = csub;
+    for (; l + 3 * CG < ncols; l += 4 * CG) {
+        double x[4][RB / 16];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double const *col = M + (size_t)(l + q * CG) * ldm + g0 + rsub;
+            #pragma unroll
+            for (int it = 0; it < RB / 16; it++) x[q][it] = col[it * 16];
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double acc = 0.0;
+            #pragma unroll
+            for (int it = 0; it < RB / 16; it++) acc += x[q][it] * pr[it];
+            acc = row16_sum(acc);
+            if (rsub == 0) atomicAdd(out + l + q * CG, acc);
+        }
+    }
+    for (; l < ncols; l += CG) {
         double const *col = M + (size_t)l * ldm + g0 + rsub;
         double acc = 0.0;
         #pragma unroll
@@ -150,6 +187,13 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     if (g < E) {
         double const *yrow = Y + g;
         int l = h;
+        for (; l + 7 * NG < j - 1; l += 8 * NG) {       // 8 loads in flight: the loop is latency-bound
+            double y[8];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) y[q] = yrow[(size_t)(l + q * NG) * ldp];
+            #pragma unroll
+            for (int q = 0; q < 8; q++) { yacc += y[q] * s_wv[l + q * NG]; pacc += y[q] * s_vrow[l + q * NG]; }
+        }
         for (; l + 3 * NG < j - 1; l += 4 * NG) {
             double y0 = yrow[(size_t)(l + 0 * NG) * ldp], y1 = yrow[(size_t)(l + 1 * NG) * ldp];
             double y2 = yrow[(size_t)(l + 2 * NG) * ldp], y3 = yrow[(size_t)(l + 3 * NG) * ldp];
@@ -170,8 +214,7 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
             double const tau = s_scal[1], beta = s_scal[2];
             #pragma unroll
             for (int q = 0; q < NG - 1; q++) { yacc += s_y[q][r]; pacc += s_pp[q][r]; }
-            double ysum = 0.0;
-            for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
+            double ysum = split_sum(ypart, ldp, g, nsplit);
             double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
             Y[(size_t)(j - 1) * ldp + g] = ynew;
             pacc += ynew * s_vrow[j - 1];
@@ -216,8 +259,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
         double const tau = s_scal[1], beta = s_scal[2];
         #pragma unroll
         for (int q = 0; q < NG - 1; q++) yacc += s_y[q][r];
-        double ysum = 0.0;
-        for (int s = 0; s < nsplit; s++) ysum += ypart[(size_t)s * ldp + g];
+        double ysum = split_sum(ypart, ldp, g, nsplit);
         Y[(size_t)(j - 1) * ldp + g] = tau * (ysum - yacc);
         if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
         else if (g > pivprev) P[(size_t)(j - 1) * ldp + g] = 0.0;

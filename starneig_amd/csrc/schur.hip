@@ -357,8 +357,32 @@ struct SchurWorkspace {
         }
     }
 };
-static SchurWorkspace g_sws;
-void schur_release_workspace() { g_sws.release(); }
+// level 0: the caller's matrix; level 1: the private AED window of a blocked AED (large_aed)
+static SchurWorkspace g_sws[2];
+
+// private matrices of the blocked AED (row S5): the window T, its Schur vectors Z, the padded
+// matrix of the re-Hessenberg step and its transformation
+struct LargeAedBuffers {
+    int cap = 0, ld = 0;
+    double *dT = nullptr, *dZ = nullptr, *dP = nullptr, *dQp = nullptr, *dZl = nullptr, *dTmp = nullptr;
+    void release() {
+        double **p[] = {&dT, &dZ, &dP, &dQp, &dZl, &dTmp};
+        for (auto q : p) if (*q) { SN_HIP_CHECK(hipFree(*q)); *q = nullptr; }
+        cap = 0;
+    }
+    void ensure(int nw) {
+        if (nw <= cap) return;
+        release();
+        cap = nw; ld = (int)roundup((size_t)nw + 1, 16);
+        size_t const bytes = (size_t)ld * ld * 8;
+        SN_HIP_CHECK(hipMalloc((void **)&dT, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dZ, bytes));
+        SN_HIP_CHECK(hipMalloc((void **)&dP, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dQp, bytes));
+        SN_HIP_CHECK(hipMalloc((void **)&dTmp, bytes));
+        SN_HIP_CHECK(hipMalloc((void **)&dZl, (size_t)128 * 128 * 8));
+    }
+};
+static LargeAedBuffers g_large;
+void schur_release_workspace() { g_sws[0].release(); g_sws[1].release(); g_large.release(); }
 
 // LAPACK iparmq-style minimum, then the reference's rules (schur/process_args.c:116-162)
 static int lapack_min_shifts(int n)
@@ -499,6 +523,178 @@ struct Driver {
         if (real) for (int i = 0; i < w; i++) { real[lo + i] = wr[i]; imag[lo + i] = wi[i]; }
         st.small_solves++;
         return 0;
+    }
+
+    // ---- blocked AED for windows above the hard limit (row S5; schur/core.c:1423-1551
+    // perform_large_aed, :1070-1252 perform_deflate_step, :783-1052 perform_deflate_finalize) ------
+    // The window is copied into a private matrix and reduced to Schur form RECURSIVELY by this same
+    // device path (level 1: chase kernels, MFMA updates, host AED on its small windows).  The
+    // deflation checks then run over <= 128-row diagonal windows from the bottom up (host::
+    // deflate_window on pinned copies; the rest of the private matrix and of its Schur vectors sees
+    // the swaps as in-place MFMA GEMMs); undeflatable blocks are carried along at the top of each
+    // window and flushed to the top of the AED window in batches (reorder chains), exactly the
+    // reference's scheme.  The spike is embedded as the first column of a padded matrix whose
+    // Hessenberg reduction (hessenberg_device) restores the Hessenberg form of the undeflated
+    // part; finally the window goes back into H and the accumulated factor reaches H and Q through
+    // apply_transform.  Nothing outside the private matrices is touched before the outcome is known.
+    void window_updates(LargeAedBuffers &L, int nw, int wb, int w)
+    {
+        // T(0:wb, win) <- . Zl ; T(win, we:nw) <- Zl^T . ; Z(:, win) <- . Zl   (w <= 128: in place)
+        if (wb > 0) dgemm_right_inplace(ts, wb, w, L.dZl, w, L.dT + (size_t)wb * L.ld, L.ld);
+        int const rc = nw - (wb + w);
+        if (rc > 0) dgemm_left_inplace(ts, w, rc, L.dZl, w, L.dT + (size_t)(wb + w) * L.ld + wb, L.ld);
+        dgemm_right_inplace(ts, nw, w, L.dZl, w, L.dZ + (size_t)wb * L.ld, L.ld);
+        st.gemm_flops += 2.0 * w * w * ((double)wb + rc + nw);
+    }
+    void window_to_host(LargeAedBuffers &L, int wb, int w, int ldh)
+    {
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hWin, (size_t)ldh * 8, L.dT + (size_t)wb * L.ld + wb, (size_t)L.ld * 8,
+            (size_t)w * 8, w, hipMemcpyDeviceToHost, ts));
+        SN_HIP_CHECK(hipStreamSynchronize(ts));
+        for (int j = 0; j < w; j++) for (int i = 0; i < w; i++) ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
+    }
+    void window_to_device(LargeAedBuffers &L, int wb, int w, int ldh)
+    {
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dT + (size_t)wb * L.ld + wb, (size_t)L.ld * 8, ws.hWin, (size_t)ldh * 8,
+            (size_t)w * 8, w, hipMemcpyHostToDevice, ts));
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dZl, (size_t)w * 8, ws.hZ, (size_t)ldh * 8, (size_t)w * 8, w,
+            hipMemcpyHostToDevice, ts));
+    }
+
+    host::AedResult large_aed(int kw, int nw, double sub, double thres, double *spike, double *sr, double *si)
+    {
+        host::AedResult res{0, 0, 0};
+        LargeAedBuffers &L = g_large;
+        L.ensure(nw);
+        int const ld = L.ld;
+        constexpr int WD = 128;                 // reorder window (in-place update tiles)
+        constexpr int WDD = 96;                 // deflation window: its undeflatable blocks must fit a reorder window with room to move
+        copy_matrix(ts, nw, nw, H + (size_t)kw * ldH + kw, ldH, L.dT, ld);
+        set_matrix(ts, nw, nw, 0.0, 1.0, L.dZ, ld);
+        // (1) Schur form of the window, recursively on the device
+        std::vector<double> wr(nw), wi(nw);
+        int const rc1 = schur_device(ts, nw, L.dT, ld, L.dZ, ld, wr.data(), wi.data(), SchurParams{}, nullptr, -1, 1);
+        SN_HIP_CHECK(hipStreamSynchronize(ts));
+        if (rc1 != STARNEIG_SUCCESS) {          // no usable Schur form: report the shifts we have, deflate nothing
+            res.failed = 1;
+            res.shifts = host::order_shifts(nw, wr.data(), wi.data());
+            for (int k = 0; k < res.shifts; k++) { sr[k] = wr[k]; si[k] = wi[k]; }
+            return res;
+        }
+        // (2) the spike row sub * Z(0,:) and the block structure
+        std::vector<double> sp(nw), tsub(nw, 0.0);
+        SN_HIP_CHECK(hipMemcpy2DAsync(sp.data(), 8, L.dZ, (size_t)ld * 8, 8, nw, hipMemcpyDeviceToHost, ts));
+        if (nw > 1)
+            SN_HIP_CHECK(hipMemcpy2DAsync(tsub.data(), 8, L.dT + 1, (size_t)(ld + 1) * 8, 8, nw - 1, hipMemcpyDeviceToHost, ts));
+        SN_HIP_CHECK(hipStreamSynchronize(ts));
+        for (int j = 0; j < nw; j++) sp[j] *= sub;
+        // (3) deflation windows, bottom up.  [0,top) final undeflatable, [top, bottom-carried)
+        // unchecked, [bottom-carried, bottom) carried undeflatable, [bottom, nw) deflated.
+        int top = 0, bottom = nw, carried = 0;
+        while (top < bottom - carried) {
+            int const we = bottom;
+            int wb = std::max(top, we - WDD);
+            if (wb > top && tsub[wb - 1] != 0.0) wb++;          // do not cut a 2x2 block
+            int const w = we - wb, ldh = host_ld(w);
+            window_to_host(L, wb, w, ldh);
+            int und = 0;
+            int const rej = host::deflate_window(w, ws.hWin, ldh, ws.hZ, ldh, sp.data() + wb, sub, thres, carried, &und);
+            window_to_device(L, wb, w, ldh);
+            window_updates(L, nw, wb, w);
+            SN_HIP_CHECK(hipStreamSynchronize(ts));
+            for (int i = 0; i + 1 < w; i++) tsub[wb + i] = ws.hWin[(size_t)i * ldh + i + 1];
+            bottom = wb + und; carried = und;
+            if (rej) { top = bottom; carried = 0; break; }      // swap rejected: stop testing
+            if (wb == top) { top = bottom; carried = 0; break; }
+            if (carried >= WDD / 2 || bottom - carried - top < 2) {
+                // flush the carried blocks to the top of the AED window (reorder chain)
+                int ge = bottom;                                // group = [ge - carried, ge)
+                std::vector<int> marks(WD);
+                while (ge - carried > top) {
+                    int rb = std::max(top, ge - WD);
+                    if (rb > top && tsub[rb - 1] != 0.0) rb++;
+                    int const rw = ge - rb, rldh = host_ld(rw);
+                    window_to_host(L, rb, rw, rldh);
+                    for (int i = 0; i < rw; i++) marks[i] = (i >= rw - carried) ? 1 : 0;
+                    int failed = 0;
+                    int const placed = host::reorder_window(rw, ws.hWin, rldh, ws.hZ, rldh, marks.data(), &failed);
+                    // spike segment <- spike * Zl
+                    {
+                        std::vector<double> t(rw);
+                        for (int j = 0; j < rw; j++) { double v = 0.0; for (int k = 0; k < rw; k++) v += sp[rb + k] * ws.hZ[(size_t)j * rldh + k]; t[j] = v; }
+                        for (int j = 0; j < rw; j++) sp[rb + j] = t[j];
+                    }
+                    window_to_device(L, rb, rw, rldh);
+                    window_updates(L, nw, rb, rw);
+                    SN_HIP_CHECK(hipStreamSynchronize(ts));
+                    for (int i = 0; i + 1 < rw; i++) tsub[rb + i] = ws.hWin[(size_t)i * rldh + i + 1];
+                    if (failed || placed != carried) {
+                        // a rejected swap leaves part of the group behind: everything from here up
+                        // counts as undeflatable, the deflation checks end
+                        top = bottom; carried = 0; ge = top; break;
+                    }
+                    ge = rb + carried;
+                }
+                if (carried > 0) { top += carried; carried = 0; }
+            }
+        }
+        if (carried > 0) { top = bottom; carried = 0; }
+        int const ns = top, nd = nw - ns;
+        // shifts: the eigenvalues of the undeflated leading part (all of them if it is tiny)
+        {
+            std::vector<double> dg(nw), sup(nw, 0.0);
+            SN_HIP_CHECK(hipMemcpy2DAsync(dg.data(), 8, L.dT, (size_t)(ld + 1) * 8, 8, nw, hipMemcpyDeviceToHost, ts));
+            if (nw > 1)
+                SN_HIP_CHECK(hipMemcpy2DAsync(sup.data(), 8, L.dT + ld, (size_t)(ld + 1) * 8, 8, nw - 1, hipMemcpyDeviceToHost, ts));
+            SN_HIP_CHECK(hipStreamSynchronize(ts));
+            int const cnt = ns >= 2 ? ns : nw;
+            for (int i = 0; i < cnt; i++) {
+                if (i + 1 < cnt && tsub[i] != 0.0) {
+                    double a = dg[i], b = sup[i], c = tsub[i], d = dg[i + 1], cs, sn_;
+                    host::lanv2(a, b, c, d, wr[i], wi[i], wr[i + 1], wi[i + 1], cs, sn_);
+                    i++;
+                } else { wr[i] = dg[i]; wi[i] = 0.0; }
+            }
+            res.shifts = host::order_shifts(cnt, wr.data(), wi.data());
+            for (int k = 0; k < res.shifts; k++) { sr[k] = wr[k]; si[k] = wi[k]; }
+        }
+        res.deflated = nd;
+        if (nd == 0) return res;                // H and Q were never touched
+        // (4) spike + Hessenberg form of the undeflated part
+        for (int j = 0; j < nw; j++) spike[j] = (j < ns) ? sp[j] : 0.0;
+        if (ns > 1 && sub != 0.0) {
+            int const np = ns + 1;
+            set_matrix(ts, np, np, 0.0, 1.0, L.dQp, ld);
+            set_matrix(ts, np, np, 0.0, 1.0, L.dP, ld);
+            copy_matrix(ts, ns, ns, L.dT, ld, L.dP + ld + 1, ld);
+            SN_HIP_CHECK(hipMemcpyAsync(L.dP + 1, sp.data(), (size_t)ns * 8, hipMemcpyHostToDevice, ts));
+            SN_HIP_CHECK(hipStreamSynchronize(ts));     // sp is pageable
+            int pw = (int)(0.001875596476 * np + 273.5908216); pw = std::max(64, (pw + 7) / 8 * 8);
+            hessenberg_device(ts, np, 0, np, pw, L.dP, ld, L.dQp, ld, nullptr);
+            // U = Qp(1:,1:):  T(0:ns, ns:nw) <- U^T . ;  Z(:, 0:ns) <- . U ;  T(0:ns,0:ns) <- P(1:,1:)
+            double const *U = L.dQp + ld + 1;
+            if (nd > 0) {
+                dgemm(ts, 'T', 'N', ns, nd, ns, 1.0, U, ld, L.dT + (size_t)ns * ld, ld, 0.0, L.dTmp, ld);
+                copy_matrix(ts, ns, nd, L.dTmp, ld, L.dT + (size_t)ns * ld, ld);
+            }
+            dgemm(ts, 'N', 'N', nw, ns, ns, 1.0, L.dZ, ld, U, ld, 0.0, L.dTmp, ld);
+            copy_matrix(ts, nw, ns, L.dTmp, ld, L.dZ, ld);
+            copy_matrix(ts, ns, ns, L.dP + ld + 1, ld, L.dT, ld);
+            SN_HIP_CHECK(hipMemcpyAsync(spike, L.dP + 1, 8, hipMemcpyDeviceToHost, ts));
+            SN_HIP_CHECK(hipStreamSynchronize(ts));
+            st.gemm_flops += 2.0 * ns * ns * ((double)nd + nw);
+        }
+        // (5) window back into H, coupling entry, off-window updates of H and Q
+        copy_matrix(ts, nw, nw, L.dT, ld, H + (size_t)kw * ldH + kw, ldH);
+        if (sub != 0.0)
+            hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, ts,
+                H + (size_t)(kw - 1) * ldH + kw, spike[0]);
+        apply_transform(kw, nw, L.dZ, ld);
+        // the caller reads the deflated diagonal blocks from the host copy of the window
+        int const ldh = host_ld(nw);
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hWin, (size_t)ldh * 8, L.dT, (size_t)ld * 8, (size_t)nw * 8, nw,
+            hipMemcpyDeviceToHost, ts));
+        return res;
     }
 
     // Lazy parts of the window steps: columns [ihi, n) of the left updates, rows [0, T0) of the
@@ -711,12 +907,14 @@ struct Driver {
 } // namespace
 
 int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int ldQ,
-    double *real, double *imag, SchurParams const &prm, SchurStats *stats, int q_rows)
+    double *real, double *imag, SchurParams const &prm, SchurStats *stats, int q_rows, int level)
 {
     // the whole reduction runs on the library's own stream pair (never on the legacy NULL
     // stream), fenced against the caller's stream at entry and exit
-    static hipStream_t own = nullptr;
-    static hipEvent_t fence = nullptr;
+    static hipStream_t own_[2] = {nullptr, nullptr};
+    static hipEvent_t fence_[2] = {nullptr, nullptr};
+    hipStream_t &own = own_[level];
+    hipEvent_t &fence = fence_[level];
     if (!own) {
         // The critical stream gets the highest priority.  Besides the scheduling preference this
         // puts it into another pool of hardware queues than the far and lazy streams: the runtime
@@ -742,7 +940,13 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // where the host kernel falls out of cache); explicit conf values are honoured up to 1024
     nw_default = std::min(nw_default, 160);
     ns_default = std::min(ns_default, 106);
-    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 1024) : nw_default;
+    // AED windows above the hard limit (process_args.c:372-398, default 300) are reduced by the
+    // blocked device path (Driver::large_aed, row S5), the others by the sequential host kernel;
+    // the private window of a blocked AED (level 1) always takes the small defaults
+    int const hard_limit = prm.aed_parallel_hard_limit > 0 ? prm.aed_parallel_hard_limit : 300;
+    int nw_conf = prm.aed_window_size > 0 ? prm.aed_window_size : nw_default;
+    if (level > 0) nw_conf = std::min(nw_conf, std::min(hard_limit, 300));
+    nw_conf = std::min(nw_conf, std::max(4, n));
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : ns_default;
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
     ns_conf = std::max(2, ns_conf - ns_conf % 2);
@@ -751,7 +955,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 40;
     int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
 
-    SchurWorkspace &ws = g_sws;
+    SchurWorkspace &ws = g_sws[level];
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});
     // Shift multiplicity: every shift pair of an AED drives `reuse` bulges of the following
     // sweep (the AED window bounds the number of distinct shifts, the host AED kernel bounds the
@@ -906,20 +1110,30 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         if (kw > ilo || (open_top && kw > d.sw.ilo)) sub = ws.hSub[kw - 1];
         int const ldh = Driver::host_ld(nw);
         if (!la_now && kw < ws.guard_row) d.set_guard_row(kw - 4 * nw);
-        d.download_window(kw, nw, ws.hWin, ldh);
+        host::AedResult ar;
+        bool const blocked = level == 0 && nw > hard_limit;
         double t_aed0 = wall();
-        host::AedResult ar = host::aed_window(nw, ws.hWin, ldh, ws.hZ, ldh, sub, thres,
-            spike.data(), sr.data(), si.data());
-        d.st.aed_host_s += wall() - t_aed0;
+        if (blocked) {
+            ar = d.large_aed(kw, nw, sub, thres, spike.data(), sr.data(), si.data());
+            d.st.aed_host_s += wall() - t_aed0;
+        } else {
+            d.download_window(kw, nw, ws.hWin, ldh);
+            t_aed0 = wall();
+            ar = host::aed_window(nw, ws.hWin, ldh, ws.hZ, ldh, sub, thres,
+                spike.data(), sr.data(), si.data());
+            d.st.aed_host_s += wall() - t_aed0;
+        }
         d.st.aeds++;
         aeds_since_sweep++;
         if (ar.deflated > 0) {
-            d.upload_window(kw, nw, ws.hWin, ldh);
-            d.upload_matrix(ws.dZ, ws.hZ, ldh, nw);
-            if (sub != 0.0)
-                hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, d.ts,
-                    dH + (size_t)(kw - 1) * ldH + kw, spike[0]);
-            d.apply_transform(kw, nw, ws.dZ, nw);
+            if (!blocked) {
+                d.upload_window(kw, nw, ws.hWin, ldh);
+                d.upload_matrix(ws.dZ, ws.hZ, ldh, nw);
+                if (sub != 0.0)
+                    hipLaunchKernelGGL(schur_set_entry_kernel, dim3(1), dim3(1), 0, d.ts,
+                        dH + (size_t)(kw - 1) * ldH + kw, spike[0]);
+                d.apply_transform(kw, nw, ws.dZ, nw);
+            }
             SN_HIP_CHECK(hipStreamSynchronize(d.ts));
             if (real) {
                 std::vector<double> wr(nw), wi(nw);

@@ -13,9 +13,12 @@ void lanv2(double &a, double &b, double &c, double &d,
     double &rt1r, double &rt1i, double &rt2r, double &rt2i, double &cs, double &sn);
 int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi);
 int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to);
+int deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,
+    double thres, int carried, int *undeflated);
 int reorder_window(int w, double *T, int ldt, double *Z, int ldz, int *sel, int *failed);
 void extract_eigenvalues(int n, const double *T, int ldt, double *wr, double *wi);
 int extract_shifts(int n, const double *T, int ldt, double *wr, double *wi);
+int order_shifts(int n, double *wr, double *wi);
 AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     double thres, double *spike, double *sr, double *si);
 

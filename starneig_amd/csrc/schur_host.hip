@@ -451,6 +451,12 @@ void extract_eigenvalues(int n, const double *T, int ldt, double *wr, double *wi
 int extract_shifts(int n, const double *T, int ldt, double *wr, double *wi)
 {
     extract_eigenvalues(n, T, ldt, wr, wi);
+    return order_shifts(n, wr, wi);
+}
+
+// ordering / pairing of a list of eigenvalues as shifts (schur/cpu_utils.c:3522-3594)
+int order_shifts(int n, double *wr, double *wi)
+{
     // zero / non-finite shifts go to the end and are dropped (cpu_utils.c:3529-3552)
     int end = n;
     for (int i = end - 1; i >= 0; i--) {
@@ -512,6 +518,67 @@ static void hessenberg_small(int nw, int ns, double *T, int ldt, double *Z, int 
             for (int j = 0; j < len; j++) Z_(i, k + 1 + j) -= s * v[j];
         }
     }
+}
+
+// ---- one deflation window of the blocked AED (schur/cpu.c:638-1006 starneig_cpu_deflate,
+// driven by schur/core.c:1070-1252) ----------------------------------------------------------
+// T: w x w quasi-triangular diagonal window of the (already Schur-reduced) AED window; the
+// bottom `carried` rows hold blocks that an earlier deflation window found undeflatable, the
+// rows above them are unchecked.  spike[0:w] is the window's segment of the spike row
+// sub * Z_aed(0,:).  The carried blocks are moved to the top of the window, then the unchecked
+// blocks are tested from the bottom (LAPACK dlaqr3 order: a block is tested when it is the last
+// undeflated one; an undeflatable block joins the carried ones at the top).  On return
+// [0, *undeflated) holds the undeflatable blocks, [*undeflated, w) the deflated ones, Z the
+// accumulated swaps and spike <- spike * Z.  Returns 0, or 1 if a swap was rejected (everything
+// above the rejected block counts as undeflatable then).
+int deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,
+    double thres, int carried, int *undeflated)
+{
+    int rc = 0;
+    // (1) carried blocks to the top, in order
+    int top = 0;
+    for (int i = w - carried; i < w;) {
+        int const bs = (i + 1 < w && T_(i + 1, i) != 0.0) ? 2 : 1;
+        if (i > top) {
+            int const at = move_block_up(w, T, ldt, Z, ldz, i, top);
+            if (at != top) { *undeflated = w; rc = 1; goto done; }   // nothing can be tested behind it
+        }
+        top += bs; i += bs;
+    }
+    {
+        // (2) test the unchecked blocks, now in [top, w), from the bottom
+        const double ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)w / ulp);
+        auto cur = [&](int col) { double v = 0.0; for (int k = 0; k < w; k++) v += spike[k] * Z_(k, col); return v; };
+        int i = w - 1;
+        while (top <= i) {
+            bool const two = (top <= i - 1 && T_(i, i - 1) != 0.0);
+            double sp = std::fabs(cur(i));
+            if (two) sp = std::max(sp, std::fabs(cur(i - 1)));
+            bool deflatable;
+            if (thres > 0.0) deflatable = sp < thres;
+            else {
+                double foo = std::fabs(T_(i, i));
+                if (two) foo += std::sqrt(std::fabs(T_(i, i - 1))) * std::sqrt(std::fabs(T_(i - 1, i)));
+                if (foo == 0.0) foo = std::fabs(sub);
+                deflatable = sp < std::max(smlnum, ulp * foo);
+            }
+            int const bs = two ? 2 : 1;
+            if (deflatable) i -= bs;
+            else {
+                int const at = move_block_up(w, T, ldt, Z, ldz, i - bs + 1, top);
+                if (at != top) { top = i + 1; rc = 1; break; }
+                top += bs;
+            }
+        }
+        *undeflated = top;
+    }
+done:
+    {
+        std::vector<double> ns(w);
+        for (int j = 0; j < w; j++) { double v = 0.0; for (int k = 0; k < w; k++) v += spike[k] * Z_(k, j); ns[j] = v; }
+        for (int j = 0; j < w; j++) spike[j] = ns[j];
+    }
+    return rc;
 }
 
 // ---- aggressive early deflation on a host window (schur/cpu_utils.c:2837-3046) ---------
@@ -623,6 +690,10 @@ int sn_internal_small_schur(int n, double *T, int ldt, double *Z, int ldz, doubl
 __attribute__((visibility("default")))
 int sn_internal_move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
 { return sn::host::move_block_up(n, T, ldt, Z, ldz, from, to); }
+__attribute__((visibility("default")))
+int sn_internal_deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,
+    double thres, int carried, int *undeflated)
+{ return sn::host::deflate_window(w, T, ldt, Z, ldz, spike, sub, thres, carried, undeflated); }
 __attribute__((visibility("default")))
 int sn_internal_reorder_window(int w, double *T, int ldt, double *Z, int ldz, int *sel, int *failed)
 { return sn::host::reorder_window(w, T, ldt, Z, ldz, sel, failed); }

@@ -258,3 +258,40 @@ def test_device_schur_without_q(node):
     torch.cuda.synchronize()
     assert torch.equal(tH1, tH2)
     assert np.array_equal(real1, real2) and np.array_equal(imag1, imag2)
+
+
+@pytest.mark.parametrize("n,nw,ns", [(2500, 400, 300), (4000, 640, 480)])
+def test_blocked_aed_for_windows_above_the_hard_limit(node, n, nw, ns):
+    """Row S5 (schur/core.c:1423-1551, :1070-1252, :783-1052): AED windows above
+    aed_parallel_hard_limit (default 300) take the blocked device path -- recursive Schur
+    reduction of the private window, windowed deflation checks with carried / flushed
+    undeflatable blocks, device re-Hessenberg.  The reference's own window rule 0.08 n gives
+    320 at n = 4000; same acceptance checks, same spectrum as the default configuration."""
+    import torch
+    tA0 = node.device_matrix(n)
+    assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
+    tH0 = tA0.clone(); tQ0 = node.device_matrix(n)
+    node.set_matrix_device(tQ0, n, n, 0.0, 1.0)
+    assert node.hessenberg_device(tH0, tQ0, n=n) == 0
+    tH, tQ = tH0.clone(), tQ0.clone()
+    rc, real0, imag0, st0 = node.schur_device(tH, tQ, n=n)
+    assert rc == 0
+    conf = node.schur_init_conf()
+    conf.aed_window_size, conf.shift_count = nw, ns
+    tH, tQ = tH0.clone(), tQ0.clone()
+    rc, real, imag, st = node.schur_device(tH, tQ, n=n, conf=conf)
+    torch.cuda.synchronize()
+    assert rc == 0 and st["aeds"] > 0 and st["aeds"] < st0["aeds"]
+    rc, chk = node.check_device(tQ, tH, tA0, n=n)
+    assert rc == 0 and chk["below_subdiagonal"] == 0
+    assert chk["residual_u"] < WARN_U and chk["orthogonality_u"] < WARN_U
+    assert O.check_schur_form(to_host(tH)) == 0
+    assert O.match_eigenvalues(real + 1j * imag, real0 + 1j * imag0) < 1e4
+    # a hard limit above the window sends the same window through the sequential host kernel
+    conf.aed_parallel_hard_limit = 1000
+    tH, tQ = tH0.clone(), tQ0.clone()
+    rc, real2, imag2, st2 = node.schur_device(tH, tQ, n=n, conf=conf)
+    assert rc == 0
+    assert O.match_eigenvalues(real2 + 1j * imag2, real0 + 1j * imag0) < 1e4
+    print(f"n={n} window {nw}: blocked {st['total_ms']:.0f} ms ({st['aeds']} AEDs, {st['sweeps']} sweeps), "
+          f"host kernel {st2['total_ms']:.0f} ms ({st2['aeds']} AEDs), default {st0['total_ms']:.0f} ms ({st0['aeds']} AEDs)")
