@@ -1000,17 +1000,26 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     d.ts = s;
     d.nq = (q_rows >= 0) ? q_rows : n;
     d.spw_cap = prm.shifts_per_window;
-    // The multiplicity adapts to how the iteration converges: a sweep gets as many copies of its
-    // shifts as AEDs have run since the previous sweep was started, at most `reuse`.  On quickly
-    // converging (random dense) inputs the AEDs chain -- ~11 per sweep at n = 20000 -- and the
-    // multiplicity stays at its maximum; on slowly converging structured inputs (all-ones
-    // Hessenberg, Toeplitz tridiagonal: two or three AEDs per sweep) it is 1, where repeated
-    // shifts would only add chain passes, i.e. rounding error (n = 8000: residual 1205 u at a
-    // fixed multiplicity of 4, 737 u at 1; LAPACK dhseqr on the same matrix: 333 u).
-    int aeds_since_sweep = 0;
+    // The multiplicity adapts to how the iteration converges.  On quickly converging (random
+    // dense) inputs the AEDs chain between two sweeps -- 11 of them per sweep at n = 20000, 7 at
+    // n = 8000 -- and repeated shifts cut the number of sweeps; on slowly converging structured
+    // inputs (all-ones Hessenberg, Toeplitz tridiagonal: 3-4 AEDs per sweep at full multiplicity)
+    // they only add chain passes, i.e. rounding error (n = 8000: residual 1205 u at a fixed
+    // multiplicity of 4, 737 u at 1; LAPACK dhseqr on the same matrix: 333 u).  Rule: full
+    // multiplicity to begin with; whenever four consecutive sweeps were preceded by fewer than
+    // 5 AEDs on average it is switched off for the rest of the reduction.
+    int aeds_since_sweep = 0, group_sweeps = -1, group_aeds = 0;
+    bool multiplicity_on = true;
     auto replicate = [&](int nsh) {
-        int const m = reuse_env ? reuse : (aeds_since_sweep >= 4 ? std::min(reuse, aeds_since_sweep) : 1);
+        if (!reuse_env && multiplicity_on) {
+            if (group_sweeps >= 0) group_aeds += aeds_since_sweep;     // (the first sweep's chain does not count)
+            if (++group_sweeps == 4) {
+                if (group_aeds < 20) multiplicity_on = false;
+                group_sweeps = 0; group_aeds = 0;
+            }
+        }
         aeds_since_sweep = 0;
+        int const m = (reuse_env || multiplicity_on) ? reuse : 1;
         for (int r = 1; r < m; r++)
             for (int k = 0; k < nsh; k++) { sr[r * nsh + k] = sr[k]; si[r * nsh + k] = si[k]; }
         return nsh * m;
