@@ -30,10 +30,10 @@ MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (spec; SURVEY.md secti
 
 def pmc_traffic_ratio():
     """HBM traffic / algorithmic bytes of the panel gemv from the committed PMC passes
-    (profiles/r1_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    (profiles/r2_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_gemv_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_gemv_pmc_traffic.json")) as f:
             return json.load(f)["traffic_over_algorithmic"]
     except Exception:
         return None
@@ -395,8 +395,8 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": (ratio * sb / nl) if (ratio and nl) else None,
                 "traffic_note": "avg algorithmic bytes per launch x PMC ratio "
-                                "(2*FETCH_SIZE+WRITE_SIZE)/algorithmic measured on the 312 "
-                                "first-panel launches at n=20000, profiles/r1_gemv_pmc_traffic.json",
+                                "(2*FETCH_SIZE+WRITE_SIZE)/algorithmic measured on the 624 launches of "
+                                "the first two panels at n=20000, profiles/r2_gemv_pmc_traffic.json",
                 "launches_timed": nl,
                 "avg_launch_us": (sm / nl * 1e3) if nl else None,
                 "avg_launch_bytes": (sb / nl) if nl else None,
