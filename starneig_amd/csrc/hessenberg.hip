@@ -618,16 +618,6 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             // it from there: temporal loads (the streaming, non-temporal ones bypass the caches).
             // Measured: 4 % on the whole reduction at n = 6000, nothing at n = 20000.
             static long const cache_bytes = (getenv("SN_HESS_CACHE_MB") ? atol(getenv("SN_HESS_CACHE_MB")) : 256L) << 20;
-            static int const exp_mode = getenv("SN_HESS_EXP") ? atoi(getenv("SN_HESS_EXP")) : 0;   // experiments
-            if (exp_mode == 3 && aligned) {     // no shadow work at all (WRONG results; timing only)
-                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(row_tiles * nsplit), dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, 0, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
-            } else if (exp_mode == 2 && aligned) {     // shadow work as a launch of its own
-                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(nshadow), dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
-                hipLaunchKernelGGL((hess_gemv_kernel<16, true>), dim3(row_tiles * nsplit), dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, 0, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
-            } else
             if (aligned && (long)m * ncols * 8 <= cache_bytes)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, false>), grid, dim3(256), 0, s,
                     dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
@@ -679,8 +669,6 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
 
         // ---- non-critical updates on the side stream (core.c:321-340) ----
         hipStream_t q = getenv("SN_HESS_NOSIDE") ? s : ws.side;
-        static bool const skip_side = getenv("SN_HESS_EXP") && atoi(getenv("SN_HESS_EXP")) == 1;  // timing experiment: WRONG results
-        if (skip_side) { SN_HIP_CHECK(hipEventRecord(ws.side_done[buf], q)); if (timed) { SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q)); SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 3], q)); } continue; }
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
         if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)

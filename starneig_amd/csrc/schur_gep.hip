@@ -466,40 +466,68 @@ struct GepDriver {
     // (host::gep_push_inf_window), the rows and columns outside a window see the accumulated
     // rotations through the usual GEMM updates -- and deflated there: A(to+1,to) = 0, B(to,to) = 0
     // exactly, eigenvalue (A(to,to), 0).  Returns the number of deflated eigenvalues.
+    double prof_inf_s = 0.0; int prof_inf_windows = 0;
     int push_infinite(int ilo, int ihi, double thres_inf, double *real, double *imag, double *beta)
     {
+        double const t_begin = wall();
         int const W = std::min(128, ws.nwmax);
-        int to = ilo, count = 0;
+        int lo = ilo, hi = ihi, count = 0;      // the block shrinks from the end an eigenvalue leaves through
         std::vector<double> dg(ihi - ilo);
-        while (to + 1 < ihi) {
-            int const len = ihi - to;
-            SN_HIP_CHECK(hipMemcpy2DAsync(dg.data(), 8, B + (size_t)to * ldB + to, (size_t)(ldB + 1) * 8, 8, len,
+        auto identity = [&](int w, int ldh) {
+            for (int j = 0; j < w; j++)
+                for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
+        };
+        while (lo + 1 < hi) {
+            int const len = hi - lo;
+            SN_HIP_CHECK(hipMemcpy2DAsync(dg.data(), 8, B + (size_t)lo * ldB + lo, (size_t)(ldB + 1) * 8, 8, len,
                 hipMemcpyDeviceToHost, s));
             SN_HIP_CHECK(hipStreamSynchronize(s));
             int z = -1;
-            for (int i = 0; i < len; i++) if (std::fabs(dg[i]) < thres_inf) { z = to + i; break; }
+            for (int i = 0; i < len; i++) if (std::fabs(dg[i]) < thres_inf) { z = lo + i; break; }
             if (z < 0) break;
-            int cur = z;
             double alpha = 0.0;
-            for (;;) {
-                int const we = std::min(ihi, cur + 2), wb = std::max(to, we - W), w = we - wb;
-                int const ldh = host_ld(w);
-                download_windows(wb, w);
-                for (int j = 0; j < w; j++)
-                    for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
-                bool const last = (wb == to);
-                host::gep_push_inf_window(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, cur - wb, 0, last ? 1 : 0);
-                if (last) alpha = ws.hA[0];
-                upload_windows(wb, w);
-                apply_transform(wb, w, ws.dQl, ws.dZl, w);
-                SN_HIP_CHECK(hipStreamSynchronize(s));
-                cur = wb;
-                if (last) break;
+            int cur = z;
+            // towards the nearer end of the block (the zeros that the iteration itself produces sit
+            // in the AED region at the bottom: one window; the reference pushes to the top only)
+            if (z - lo <= hi - 1 - z) {
+                for (;;) {
+                    int const we = std::min(hi, cur + 2), wb = std::max(lo, we - W), w = we - wb;
+                    int const ldh = host_ld(w);
+                    download_windows(wb, w);
+                    identity(w, ldh);
+                    bool const last = (wb == lo);
+                    host::gep_push_inf_window(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, cur - wb, 0, last ? 1 : 0);
+                    if (last) alpha = ws.hA[0];
+                    upload_windows(wb, w);
+                    apply_transform(wb, w, ws.dQl, ws.dZl, w);
+                    SN_HIP_CHECK(hipStreamSynchronize(s));
+                    cur = wb; prof_inf_windows++;
+                    if (last) break;
+                }
+                if (real) { real[lo] = alpha; imag[lo] = 0.0; beta[lo] = 0.0; }
+                lo++;
+            } else {
+                for (;;) {
+                    int const wb = std::max(lo, cur - 1), we = std::min(hi, wb + W), w = we - wb;
+                    int const ldh = host_ld(w);
+                    download_windows(wb, w);
+                    identity(w, ldh);
+                    bool const last = (we == hi);
+                    host::gep_push_inf_down_window(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, cur - wb, last ? 1 : 0);
+                    if (last) alpha = ws.hA[(size_t)(w - 1) * ldh + (w - 1)];
+                    upload_windows(wb, w);
+                    apply_transform(wb, w, ws.dQl, ws.dZl, w);
+                    SN_HIP_CHECK(hipStreamSynchronize(s));
+                    cur = we - 1; prof_inf_windows++;
+                    if (last) break;
+                }
+                if (real) { real[hi - 1] = alpha; imag[hi - 1] = 0.0; beta[hi - 1] = 0.0; }
+                hi--;
             }
-            if (real) { real[to] = alpha; imag[to] = 0.0; beta[to] = 0.0; }
-            to++; count++;
+            count++;
         }
         st.inf_deflated += count;
+        prof_inf_s += wall() - t_begin;
         return count;
     }
 
@@ -788,6 +816,10 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
+    if (getenv("SN_SCHUR_PROFILE"))
+        fprintf(stderr, "[qz] total %.3f s: aed_host %.3f, wait %.3f, push_inf %.3f s for %d infinite eigenvalues (%d windows); n %d sweeps %d aeds %d\n",
+            d.st.total_ms * 1e-3, d.st.aed_host_s, d.st.wait_s, d.prof_inf_s, d.st.inf_deflated, d.prof_inf_windows,
+            n, d.st.sweeps, d.st.aeds);
     if (stats) *stats = d.st;
     return rc;
 }

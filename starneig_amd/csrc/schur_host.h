@@ -27,6 +27,8 @@ void gep_extract_eigenvalues(int n, const double *S, int lds, const double *T, i
     double *ar, double *ai, double *be);
 void gep_push_inf_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int from, int to, int deflate);
+void gep_push_inf_down_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int from, int deflate);
 int gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int nq, double *ar, double *ai, double *be);
 void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,

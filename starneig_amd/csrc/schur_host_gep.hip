@@ -230,6 +230,42 @@ void gep_push_inf_window(int w, double *A_, int lda, double *B_, int ldb, double
     }
 }
 
+// The mirror image: the zero at B(from,from) is chased DOWN to the last row of the window
+// (LAPACK dhgeqz, "chase the zero to T(ILAST,ILAST)": a row rotation moves the zero one position
+// down the diagonal, a column rotation removes the fill below A's sub-diagonal).  from >= 1
+// unless row 0 is the first row of the active block.  With deflate != 0 (the window ends the
+// active block) a last column rotation annihilates A(w-1,w-2): the 1x1 block (A(w-1,w-1), 0)
+// splits off at the bottom.
+void gep_push_inf_down_window(int w, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
+    double *Z_, int ldz, int from, int deflate)
+{
+    Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
+    double c, s, r;
+    for (int jch = from; jch < w - 1; jch++) {
+        givens(B(jch, jch + 1), B(jch + 1, jch + 1), c, s, r);
+        B(jch, jch + 1) = r; B(jch + 1, jch + 1) = 0.0;
+        rot_rows(B, jch, jch + 1, jch + 2, w, c, s);
+        rot_rows(A, jch, jch + 1, jch >= 1 ? jch - 1 : 0, w, c, s);
+        rot_cols(Q, jch, jch + 1, 0, w, c, s);
+        if (jch >= 1) {
+            givens(A(jch + 1, jch), A(jch + 1, jch - 1), c, s, r);
+            A(jch + 1, jch) = r; A(jch + 1, jch - 1) = 0.0;
+            rot_cols(A, jch, jch - 1, 0, jch + 1, c, s);
+            rot_cols(B, jch, jch - 1, 0, jch, c, s);
+            rot_cols(Z, jch, jch - 1, 0, w, c, s);
+        }
+    }
+    if (deflate && w >= 2) {
+        int const il = w - 1;
+        givens(A(il, il), A(il, il - 1), c, s, r);
+        A(il, il) = r; A(il, il - 1) = 0.0;
+        rot_cols(A, il, il - 1, 0, il, c, s);
+        rot_cols(B, il, il - 1, 0, il, c, s);
+        rot_cols(Z, il, il - 1, 0, w, c, s);
+        B(il, il) = 0.0;
+    }
+}
+
 void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_, int ldt,
     double *ar, double *ai, double *be)
 {
@@ -661,6 +697,10 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
 
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
+__attribute__((visibility("default")))
+void sn_internal_gep_push_inf_down_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, int from, int deflate)
+{ sn::host::gep_push_inf_down_window(w, A, lda, B, ldb, Q, ldq, Z, ldz, from, deflate); }
 __attribute__((visibility("default")))
 void sn_internal_gep_push_inf_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int from, int to, int deflate)

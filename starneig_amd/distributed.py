@@ -123,6 +123,20 @@ def schur_sharded(tH, tQ, n=None, conf=None, group=None):
         torch.cuda.current_stream().cuda_stream, st)
     # tQ has shape (columns, ld): dimension 1 runs over the rows of the column-major matrix
     if world > 1:
+        # the row blocks of Q only fit together if every replica of H was reduced identically
+        # (the reduction is deterministic: ordered norm, no atomics on the Schur path): compare a
+        # checksum of the eigenvalues and of diag(H) across the ranks before assembling Q
+        dg = torch.diagonal(tH[:, :n])
+        chk = torch.stack([dg.sum(), (dg * dg).sum(),
+                           torch.tensor(float(real.sum()), dtype=torch.float64, device=tH.device),
+                           torch.tensor(float(np.abs(imag).sum()), dtype=torch.float64, device=tH.device),
+                           torch.tensor(float(rc), dtype=torch.float64, device=tH.device)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("starneig_amd: the replicas of H diverged in the sharded Schur leg "
+                               f"(checksums {lo.tolist()} .. {hi.tolist()})")
         tQ[:, :r0] = 0.0
         tQ[:, r1:] = 0.0
         dist.all_reduce(tQ, op=dist.ReduceOp.SUM, group=group)
