@@ -46,7 +46,7 @@ constexpr int CHASE_THREADS = 1024; // 16 waves share one window (512 threads: 1
 constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_P = UPDATE_LDS_BYTES_L > UPDATE_LDS_BYTES_R ? UPDATE_LDS_BYTES_L : UPDATE_LDS_BYTES_R;
-constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 8 * NB_MAX + 16) * 8;
+constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // W, U, two reflector buffers
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
 __device__ __forceinline__ void shift_vector(double const *W, double sr1, double si1,
@@ -65,17 +65,60 @@ __device__ __forceinline__ void shift_vector(double const *W, double sr1, double
 
 // One workgroup chases one chain of bulges through one diagonal window held in LDS
 // (the device counterpart of process_small_window, schur/cpu_utils.c:1168-1810, without
-// its QZ branches).  Per column step: (1) one lane per bulge builds its reflector,
-// (2) all lanes apply the reflectors from the left, (3) from the right to the window and
-// to the accumulated factor U.  Bulges sit 3 columns apart, so the reflectors of one step
-// touch disjoint rows/columns and commute (the LAPACK dlaqr5 argument).
-__global__ __launch_bounds__(CHASE_THREADS)
-void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+// its QZ branches).  Per column step all lanes apply the step's reflectors (a) from the left,
+// (b) from the right to the window and to the accumulated factor U; bulges sit 3 columns apart,
+// so the reflectors of one step touch disjoint rows/columns and commute (the LAPACK dlaqr5
+// argument).  The reflector of the NEXT step is built inside phase (b): lane i first applies
+// bulge i's reflector to the three window rows whose entries in the bulge's first column ARE the
+// next reflector's input, builds it from the values it holds in registers and publishes it in
+// the other half of a double buffer -- the scalar chain of divisions and a square root runs
+// beside the bulk of phase (b) instead of in a phase (and behind a barrier) of its own.
+struct ChaseReflector { double v1, v2, tau; int row0, len; };
+
+__device__ __forceinline__ void chase_publish(double *R, int *Ri, int i, double v1, double v2, double tau, int row0, int len)
+{
+    R[4 * i + 0] = v1; R[4 * i + 1] = v2; R[4 * i + 2] = tau;
+    R[4 * i + 3] = (tau != 0.0) ? (double)len : 0.0;   // all four in one 32-byte read
+    Ri[2 * i + 0] = row0; Ri[2 * i + 1] = (tau != 0.0) ? len : 0;
+}
+
+// reflector of bulge i for the step whose leading column is j (j = -1: introduction from the
+// shifts); published in LDS for all lanes and returned in registers for the lane itself
+__device__ __forceinline__ ChaseReflector chase_build(double *W, int n, int i, int j, bool have,
+    double xi0, double xi1, double xi2, double sr1, double si1, double sr2, double si2, double *R, int *Ri)
+{
+    int len = 0;
+    double beta = 0.0, v1 = 0.0, v2 = 0.0, tau = 0.0;
+    if (j >= -1 && j < n - 2) {
+        if (j == -1) {
+            double x[3];
+            shift_vector(W, sr1, si1, sr2, si2, x);
+            len = 3;
+            small_reflector(3, x, beta, v1, v2, tau);
+        } else {
+            len = (j == n - 3) ? 2 : 3;
+            double *col = W + j * LDW + j + 1;
+            // (scalars, not an array handed over by pointer: that would live in scratch memory and put
+            // a memory round trip on the serial chain of every column step)
+            double x[3];
+            x[0] = have ? xi0 : col[0]; x[1] = have ? xi1 : col[1];
+            x[2] = (len == 3) ? (have ? xi2 : col[2]) : 0.0;
+            small_reflector(len, x, beta, v1, v2, tau);
+            col[0] = beta; col[1] = 0.0;
+            if (len == 3) col[2] = 0.0;
+        }
+    }
+    chase_publish(R, Ri, i, v1, v2, tau, j + 1, len);
+    return ChaseReflector{v1, v2, tau, j + 1, (tau != 0.0) ? len : 0};
+}
+
+template <int DBG>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
+__device__ __forceinline__ void schur_chase_body(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *W = lds, *U = lds + WS_MAX * LDW, *R = U + WS_MAX * LDW;   // R: per bulge {v1,v2,tau,row0|len}
-    int *Ri = reinterpret_cast<int *>(R + 4 * NB_MAX);
+    double *W = lds, *U = lds + WS_MAX * LDW, *Rbase = U + WS_MAX * LDW;   // per bulge {v1,v2,tau,-}, two buffers
+    int *Ribase = reinterpret_cast<int *>(Rbase + 8 * NB_MAX);            // per bulge {row0, len}, two buffers
     ChaseTask const t = make_task(step, blockIdx.x);
     int const n = t.n, nb = t.nb, tid = threadIdx.x;
     bool const introduce = t.flags & 1, finalize = t.flags & 2;
@@ -85,62 +128,108 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
         W[c * LDW + r] = H[(size_t)(t.lo + c) * ldH + t.lo + r];
         U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
     }
+    // the (bulge, column) and (bulge, row) pairs a lane owns do not change from step to step
+    constexpr int L_ITEMS = (NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
+    constexpr int R_ITEMS = (2 * NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
+    int li[L_ITEMS], lc[L_ITEMS], ri[R_ITEMS], rr_[R_ITEMS];
+    #pragma unroll
+    for (int k = 0; k < L_ITEMS; k++) {
+        int const item = tid + k * CHASE_THREADS;
+        li[k] = item < nb * n ? item / n : -1; lc[k] = item - (item / n) * n;
+    }
+    #pragma unroll
+    for (int k = 0; k < R_ITEMS; k++) {
+        int const item = tid + k * CHASE_THREADS;
+        ri[k] = item < nb * n * 2 ? item / (2 * n) : -1; rr_[k] = item - (item / (2 * n)) * 2 * n;
+    }
     __syncthreads();
 
     int const left = introduce ? 2 - 3 * nb : 0;
     int const right = finalize ? n - 2 : t.right;
+    ChaseReflector mine{0.0, 0.0, 0.0, 0, 0};
+    double sr1 = 0.0, si1 = 0.0, sr2 = 0.0, si2 = 0.0;         // the lane's shift pair (used at introduction)
+    if (tid < nb && introduce) {
+        sr1 = sr[t.shift_off + 2 * tid]; si1 = si[t.shift_off + 2 * tid];
+        sr2 = sr[t.shift_off + 2 * tid + 1]; si2 = si[t.shift_off + 2 * tid + 1];
+    }
+    if (tid < nb && left < right) mine = chase_build(W, n, tid, left + 3 * tid, false, 0.0, 0.0, 0.0, sr1, si1, sr2, si2, Rbase, Ribase);
+    __syncthreads();
     for (int begin = left; begin < right; begin++) {
-        // (1) reflectors
-        if (tid < nb) {
-            int const i = tid, j = begin + 3 * i;
-            int len = 0;
-            double beta = 0.0, v1 = 0.0, v2 = 0.0, tau = 0.0;
-            if (j >= -1 && j < n - 2) {
-                if (j == -1) {
-                    double x[3];
-                    shift_vector(W, sr[t.shift_off + 2 * i], si[t.shift_off + 2 * i],
-                        sr[t.shift_off + 2 * i + 1], si[t.shift_off + 2 * i + 1], x);
-                    len = 3;
-                    small_reflector(3, x, beta, v1, v2, tau);
-                } else {
-                    len = (j == n - 3) ? 2 : 3;
-                    double *col = W + j * LDW + j + 1;
-                    small_reflector(len, col, beta, v1, v2, tau);
-                    col[0] = beta; col[1] = 0.0;
-                    if (len == 3) col[2] = 0.0;
-                }
+        int const cur = (begin - left) & 1;
+        double const *R = Rbase + cur * 4 * NB_MAX;
+        // The position of bulge i is arithmetic (row0 = begin + 3 i + 1), so an item's window entries
+        // and its reflector are fetched in ONE round of LDS reads (clamped addresses, predicated
+        // stores) instead of a chain of dependent reads -- the phases are LDS-latency-bound.
+        // (a) left: rows row0..row0+len-1, columns max(row0,0)..n-1
+        #pragma unroll
+        for (int k = 0; k < L_ITEMS; k++) {
+            int const i = li[k], c = lc[k];
+            if (i < 0 || (DBG & 1)) continue;
+            int const row0 = begin + 3 * i + 1;
+            int const rs = max(0, min(max(row0, 0), n - 3));
+            double *p = W + c * LDW + rs;
+            double const x0 = p[0], x1 = p[1], x2r = p[2];
+            d4 const rf = *reinterpret_cast<d4 const *>(R + 4 * i);      // v1, v2, tau, len
+            int const len = (int)rf.w;
+            if (len == 0 || c < row0) continue;                          // (len != 0 implies 0 <= row0 <= n-2)
+            double *q = W + c * LDW + row0;
+            double const y2 = (len == 3) ? x2r : 0.0;
+            double const y0 = (rs == row0) ? x0 : q[0], y1 = (rs == row0) ? x1 : q[1];   // len == 2 at the window end
+            double const sum = rf.z * (y0 + rf.x * y1 + rf.y * y2);
+            q[0] = y0 - sum; q[1] = y1 - sum * rf.x;
+            if (len == 3) q[2] = y2 - sum * rf.y;
+        }
+        __syncthreads();
+        // (b) right: columns row0..row0+len-1; window rows 0..min(n-1,row0+3), all rows of U.
+        // Lane i < nb owns the window rows row0+1..row0+3 of bulge i and builds the next reflector.
+        if (tid < nb && !(DBG & 4)) {
+            int const i = tid;
+            int const len = mine.len, row0 = mine.row0;
+            double xa = 0.0, xb = 0.0, xc = 0.0;
+            bool have = false;
+            if (len != 0) {
+                double const v1 = mine.v1, v2 = mine.v2, tau = mine.tau;
+                // all nine entries in one round of reads (rows clamped to the window)
+                int const r0 = min(row0 + 1, n - 1), r1 = min(row0 + 2, n - 1), r2 = min(row0 + 3, n - 1);
+                double *base = W + row0 * LDW;
+                int const c2 = (len == 3) ? 2 * LDW : LDW;
+                double a0 = base[r0], a1 = base[LDW + r0], a2 = base[c2 + r0];
+                double b0 = base[r1], b1 = base[LDW + r1], b2 = base[c2 + r1];
+                double c0 = base[r2], c1 = base[LDW + r2], c2v = base[c2 + r2];
+                if (len != 3) { a2 = 0.0; b2 = 0.0; c2v = 0.0; }
+                double const sa = tau * (a0 + v1 * a1 + v2 * a2);
+                double const sb = tau * (b0 + v1 * b1 + v2 * b2);
+                double const sc = tau * (c0 + v1 * c1 + v2 * c2v);
+                xa = a0 - sa; xb = b0 - sb; xc = c0 - sc;
+                if (row0 + 1 <= n - 1) { base[r0] = xa; base[LDW + r0] = a1 - sa * v1; if (len == 3) base[2 * LDW + r0] = a2 - sa * v2; }
+                if (row0 + 2 <= n - 1) { base[r1] = xb; base[LDW + r1] = b1 - sb * v1; if (len == 3) base[2 * LDW + r1] = b2 - sb * v2; }
+                if (row0 + 3 <= n - 1) { base[r2] = xc; base[LDW + r2] = c1 - sc * v1; if (len == 3) base[2 * LDW + r2] = c2v - sc * v2; }
+                have = true;
             }
-            R[4 * i + 0] = v1; R[4 * i + 1] = v2; R[4 * i + 2] = tau;
-            Ri[2 * i + 0] = j + 1; Ri[2 * i + 1] = (tau != 0.0) ? len : 0;
+            if (begin + 1 < right)
+                mine = chase_build(W, n, i, begin + 1 + 3 * i, have, xa, xb, xc, sr1, si1, sr2, si2,
+                    Rbase + (cur ^ 1) * 4 * NB_MAX, Ribase + (cur ^ 1) * 2 * NB_MAX);
         }
-        __syncthreads();
-        // (2) left: rows row0..row0+len-1, columns max(row0,0)..n-1   (row0 = j+1)
-        for (int item = tid; item < nb * n; item += CHASE_THREADS) {
-            int const i = item / n, c = item - i * n;
-            int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
-            if (len == 0 || c < row0) continue;
-            double const v1 = R[4 * i], v2 = R[4 * i + 1], tau = R[4 * i + 2];
-            double *p = W + c * LDW + row0;
-            double x0 = p[0], x1 = p[1], x2 = (len == 3) ? p[2] : 0.0;
-            double s = tau * (x0 + v1 * x1 + v2 * x2);
-            p[0] = x0 - s; p[1] = x1 - s * v1;
-            if (len == 3) p[2] = x2 - s * v2;
-        }
-        __syncthreads();
-        // (3) right: columns row0..row0+len-1; window rows 0..min(n-1,row0+3), all rows of U
-        for (int item = tid; item < nb * n * 2; item += CHASE_THREADS) {
-            int const i = item / (2 * n), rr = item - i * 2 * n;
-            int const len = Ri[2 * i + 1], row0 = Ri[2 * i];
-            if (len == 0) continue;
-            double *M; int r;
-            if (rr < n) { r = rr; if (r > row0 + 3) continue; M = W; }
-            else { r = rr - n; M = U; }
-            double const v1 = R[4 * i], v2 = R[4 * i + 1], tau = R[4 * i + 2];
-            double *p = M + row0 * LDW + r;
-            double x0 = p[0], x1 = p[LDW], x2 = (len == 3) ? p[2 * LDW] : 0.0;
-            double s = tau * (x0 + v1 * x1 + v2 * x2);
-            p[0] = x0 - s; p[LDW] = x1 - s * v1;
-            if (len == 3) p[2 * LDW] = x2 - s * v2;
+        #pragma unroll
+        for (int k = 0; k < R_ITEMS; k++) {
+            int const i = ri[k], rr = rr_[k];
+            if (i < 0 || (DBG & 2)) continue;
+            int const row0 = begin + 3 * i + 1;
+            int const cs = max(0, min(max(row0, 0), n - 3));            // clamped column for the reads
+            bool const inW = rr < n;
+            int const r = inW ? rr : rr - n;
+            double *M = inW ? W : U;
+            double *p = M + cs * LDW + r;
+            double const x0 = p[0], x1 = p[LDW], x2r = p[2 * LDW];
+            d4 const rf = *reinterpret_cast<d4 const *>(R + 4 * i);
+            int const len = (int)rf.w;
+            if (len == 0 || (inW && r > row0)) continue;                 // rows row0+1.. belong to lane i
+            double *q = M + row0 * LDW + r;
+            double const y2 = (len == 3) ? x2r : 0.0;
+            double const y0 = (cs == row0) ? x0 : q[0], y1 = (cs == row0) ? x1 : q[LDW];
+            double const sum = rf.z * (y0 + rf.x * y1 + rf.y * y2);
+            q[0] = y0 - sum; q[LDW] = y1 - sum * rf.x;
+            if (len == 3) q[2 * LDW] = y2 - sum * rf.y;
         }
         __syncthreads();
     }
@@ -151,6 +240,20 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
         H[(size_t)(t.lo + c) * ldH + t.lo + r] = W[c * LDW + r];
         Uo[c * WS_MAX + r] = U[c * LDW + r];
     }
+}
+
+__global__ __launch_bounds__(CHASE_THREADS)
+void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
+{
+    schur_chase_body<0>(step, H, ldH, Uout, sr, si);
+}
+template <int DBG>
+__global__ __launch_bounds__(CHASE_THREADS)
+void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
+{
+    schur_chase_body<DBG>(step, H, ldH, Uout, sr, si);
 }
 
 // Off-diagonal updates of all chains of one step (row S3).
@@ -1217,3 +1320,57 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 }
 
 } // namespace sn
+
+// ---- measurement hook (NOT part of the public C-ABI; scratch/chase_bench.py): average duration
+// of one schur_chase_kernel launch with `chains` full windows on a random Hessenberg matrix
+extern "C" __attribute__((visibility("default")))
+double sn_internal_chase_bench(int chains, int reps, int dbg)
+{
+    using namespace sn;
+    int const ws_ = WS_MAX, nbc = NB_MAX, adv = ws_ - 1 - 3 * nbc, gap = divceil(ws_ + adv, adv);
+    int const n = ws_ + adv * (gap * (chains - 1) + 4) + 200, ld = (int)roundup(n, 16);
+    double *H0, *H, *U, *sr, *si;
+    SN_HIP_CHECK(hipMalloc((void **)&H0, (size_t)ld * n * 8)); SN_HIP_CHECK(hipMalloc((void **)&H, (size_t)ld * n * 8));
+    SN_HIP_CHECK(hipMalloc((void **)&U, (size_t)chains * WS_MAX * WS_MAX * 8));
+    SN_HIP_CHECK(hipMalloc((void **)&sr, (size_t)2 * nbc * chains * 8)); SN_HIP_CHECK(hipMalloc((void **)&si, (size_t)2 * nbc * chains * 8));
+    lcg_fill(nullptr, n, n, 7u, 1, H0, ld);
+    std::vector<double> h((size_t)ld * n);
+    SN_HIP_CHECK(hipMemcpy(h.data(), H0, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < n; c++) for (int r = c + 2; r < n; r++) h[(size_t)c * ld + r] = 0.0;
+    // bulges in flight: a dense 3x3 bump every 3 columns inside every window position
+    for (int c = 0; c + 3 < n; c++) { h[(size_t)c * ld + c + 2] = 0.3; if (c % 3 == 0) h[(size_t)c * ld + c + 3] = 0.2; }
+    SN_HIP_CHECK(hipMemcpy(H0, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double> shr(2 * nbc * chains), shi(2 * nbc * chains, 0.0);
+    for (size_t k = 0; k < shr.size(); k++) shr[k] = 0.1 + 0.01 * k;
+    SN_HIP_CHECK(hipMemcpy(sr, shr.data(), shr.size() * 8, hipMemcpyHostToDevice));
+    SN_HIP_CHECK(hipMemcpy(si, shi.data(), shi.size() * 8, hipMemcpyHostToDevice));
+    SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
+        hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+    int const size = n, spc = divceil(size - ws_, adv) + 1;
+    SweepStep step{0, n, ws_, nbc, adv, gap, nbc * chains, spc, 0, 0, 0};
+    step.t = gap * (chains - 1) + 2; step.cmin = 0; step.ntasks = chains;     // every chain mid-flight
+    hipEvent_t e0, e1; SN_HIP_CHECK(hipEventCreate(&e0)); SN_HIP_CHECK(hipEventCreate(&e1));
+    double total = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        SN_HIP_CHECK(hipMemcpy(H, H0, (size_t)ld * n * 8, hipMemcpyDeviceToDevice));
+        SN_HIP_CHECK(hipEventRecord(e0, nullptr));
+        auto go = [&](auto kern) {
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+            hipLaunchKernelGGL(kern, dim3(chains), dim3(CHASE_THREADS), CHASE_LDS_BYTES, nullptr, step, H, ld, U, sr, si);
+        };
+        switch (dbg) {
+            case 1: go(schur_chase_dbg_kernel<1>); break;
+            case 2: go(schur_chase_dbg_kernel<2>); break;
+            case 3: go(schur_chase_dbg_kernel<3>); break;
+            case 4: go(schur_chase_dbg_kernel<4>); break;
+            case 7: go(schur_chase_dbg_kernel<7>); break;
+            default: go(schur_chase_kernel);
+        }
+        SN_HIP_CHECK(hipEventRecord(e1, nullptr));
+        SN_HIP_CHECK(hipEventSynchronize(e1));
+        float ms; SN_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    SN_HIP_CHECK(hipFree(H0)); SN_HIP_CHECK(hipFree(H)); SN_HIP_CHECK(hipFree(U)); SN_HIP_CHECK(hipFree(sr)); SN_HIP_CHECK(hipFree(si));
+    return total / reps * 1e3;      // microseconds
+}

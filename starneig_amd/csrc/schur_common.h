@@ -56,13 +56,18 @@ __host__ __device__ __forceinline__ void small_reflector(int len, double const *
     if ((x1 == 0.0 && x2 == 0.0) || !(m > 1e-290) || !(fmax(fabs(x1), fabs(x2)) > 1e-290)) {
         beta = x0; v1 = v2 = 0.0; tau = 0.0; return;
     }
-    double const im = 1.0 / m;
-    double a = x0 * im, b1 = x1 * im, b2 = x2 * im;
+    // scaling by a power of two (exact, no division); then ONE division serves both quotients:
+    // with t = a - bs (same sign as a, |t| = |a| + |bs|) and r = 1 / (t bs):
+    //   tau = (bs - a) / bs = -t / bs = -t^2 r,   1 / (a - bs) = bs r.
+    // (this routine sits on the serial chain of every column step of the chase kernels)
+    int const e = ilogb(m);
+    double a = scalbn(x0, -e), b1 = scalbn(x1, -e), b2 = scalbn(x2, -e);
     double bs = -copysign(sqrt(a * a + b1 * b1 + b2 * b2), a);
-    tau = (bs - a) / bs;
-    double sc = 1.0 / (a - bs);
+    double const t = a - bs, r = 1.0 / (t * bs);
+    tau = -(t * t) * r;
+    double const sc = bs * r;
     v1 = b1 * sc; v2 = b2 * sc;
-    beta = bs * m;
+    beta = scalbn(bs, e);
 }
 
 } // namespace sn
