@@ -281,6 +281,7 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
     sn::SchurParams prm;
     int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
+    prm.host_threads = g_node.cores;
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
@@ -501,6 +502,7 @@ SN_API starneig_error_t starneig_GEP_SM_Schur_expert(
     sn::SchurParams prm;
     int rc = schur_params_from_conf(conf, prm, true);
     if (rc != STARNEIG_SUCCESS) return rc;
+    prm.host_threads = g_node.cores;
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
@@ -560,6 +562,7 @@ SN_API starneig_error_t starneig_amd_gep_schur_device(
     sn::SchurParams prm;
     int rc = schur_params_from_conf(conf, prm, true);
     if (rc != STARNEIG_SUCCESS) return rc;
+    prm.host_threads = g_node.cores;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
     if (real == NULL || imag == NULL || beta == NULL) real = imag = beta = nullptr;
@@ -585,6 +588,7 @@ SN_API starneig_error_t starneig_amd_schur_device(
     sn::SchurParams prm;
     int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
+    prm.host_threads = g_node.cores;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
     if (real == NULL || imag == NULL) real = imag = nullptr;
@@ -612,6 +616,7 @@ SN_API starneig_error_t starneig_amd_schur_rows_device(
     sn::SchurParams prm;
     int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
+    prm.host_threads = g_node.cores;
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
     if (real == NULL || imag == NULL) real = imag = nullptr;

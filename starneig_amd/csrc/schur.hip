@@ -1058,6 +1058,16 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 40;
     int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
 
+    // Helper threads of the host window kernels (schur_host.hip) for the duration of this reduction:
+    // opt-in (SN_SCHUR_HELPERS=1, and starneig_node_init's cores >= 3).  Measured at n = 20000 on
+    // the GPU box: the host AED time is the same with and without them (1.45 s: the refactored
+    // serial loops already run at the speed of the pipelined ones on that CPU) and so is the leg.
+    struct HelperSession {
+        bool on;
+        explicit HelperSession(bool o) : on(o) { if (on) host::helper_session(true); }
+        ~HelperSession() { if (on) host::helper_session(false); }
+    } helper_session(level == 0 && prm.host_threads >= 3 && getenv("SN_SCHUR_HELPERS") != nullptr);
+
     SchurWorkspace &ws = g_sws[level];
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});
     // Shift multiplicity: every shift pair of an AED drives `reuse` bulges of the following

@@ -16,7 +16,154 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <immintrin.h>
+
 namespace sn { namespace host {
+
+// ---- helper threads of the sequential window kernels ------------------------------------------
+// The double-shift QR sweep of small_schur is a serial chain of 3x3 reflectors; only the part of
+// each reflector's application that the NEXT reflector depends on has to stay on that chain: the
+// rows inside the active block from the left, the columns from the right.  The two other parts
+// -- the accumulation into Z, and the left update of the columns right of the active block (the
+// already converged part of T) -- touch data the chain never reads again, so they are handed to
+// two helper threads through single-producer rings and applied there in order.  Every entry sees
+// the same operations in the same order as in the serial loop: the results are bit-identical.
+// The helpers exist only while a session is open (one Schur reduction) and `cores` >= 3.
+namespace {
+
+struct ReflOp { int k2, nr, from, kind; double a, b, c; };   // kind 0: reflector (v2, v3, t1); 1: rotation (cs, sn)
+
+struct OpRing {
+    static constexpr unsigned CAP = 2048;
+    ReflOp ops[CAP];
+    alignas(64) std::atomic<unsigned> head{0};      // next slot to write (producer)
+    alignas(64) std::atomic<unsigned> tail{0};      // next slot to read (consumer)
+    void push(ReflOp const &op) {
+        unsigned h = head.load(std::memory_order_relaxed);
+        while (h - tail.load(std::memory_order_acquire) >= CAP) _mm_pause();
+        ops[h % CAP] = op;
+        head.store(h + 1, std::memory_order_release);
+    }
+    void wait_empty() { while (tail.load(std::memory_order_acquire) != head.load(std::memory_order_relaxed)) _mm_pause(); }
+};
+
+struct Job { double *M = nullptr; int ld = 0, n = 0; };
+
+struct Helpers {
+    OpRing ring[2];                 // 0: Z accumulation, 1: left updates of the converged columns of T
+    Job job[2];
+    std::thread th[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    bool session = false, quit = false, started = false;
+
+    // Z(:, k2 : k2+nr) <- . G  (all rows): the same loops as in small_schur
+    __attribute__((noinline)) static void apply_z(Job const &jb, ReflOp const &op) {
+        double *Z = jb.M; int const ldz = jb.ld, n = jb.n;
+        if (op.kind == 1) {
+            double *__restrict__ a = &Z[(size_t)op.k2 * ldz], *__restrict__ b = &Z[(size_t)(op.k2 + 1) * ldz];
+            for (int i = 0; i < n; i++) { double x = a[i], y = b[i]; a[i] = op.a * x + op.b * y; b[i] = op.a * y - op.b * x; }
+            return;
+        }
+        double const v2 = op.a, v3 = op.b, t1 = op.c, t2 = t1 * v2, t3 = t1 * v3;
+        double *__restrict__ z0 = &Z[(size_t)op.k2 * ldz], *__restrict__ z1 = &Z[(size_t)(op.k2 + 1) * ldz];
+        if (op.nr == 3) {
+            double *__restrict__ z2 = &Z[(size_t)(op.k2 + 2) * ldz];
+            for (int j = 0; j < n; j++) {
+                double sum = z0[j] + v2 * z1[j] + v3 * z2[j];
+                z0[j] -= sum * t1; z1[j] -= sum * t2; z2[j] -= sum * t3;
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                double sum = z0[j] + v2 * z1[j];
+                z0[j] -= sum * t1; z1[j] -= sum * t2;
+            }
+        }
+    }
+    // T(k2 : k2+nr, from : n) <- G^T .   (columns right of the active block)
+    __attribute__((noinline)) static void apply_left(Job const &jb, ReflOp const &op) {
+        double *T = jb.M; int const ldt = jb.ld, n = jb.n, k2 = op.k2;
+        if (op.kind == 1) {
+            for (int j = op.from; j < n; j++) {
+                double x = T[(size_t)j * ldt + k2], y = T[(size_t)j * ldt + k2 + 1];
+                T[(size_t)j * ldt + k2] = op.a * x + op.b * y; T[(size_t)j * ldt + k2 + 1] = op.a * y - op.b * x;
+            }
+            return;
+        }
+        double const v2 = op.a, v3 = op.b, t1 = op.c, t2 = t1 * v2, t3 = t1 * v3;
+        if (op.nr == 3) {
+            for (int j = op.from; j < n; j++) {
+                double *p = &T[(size_t)j * ldt + k2];
+                double sum = p[0] + v2 * p[1] + v3 * p[2];
+                p[0] -= sum * t1; p[1] -= sum * t2; p[2] -= sum * t3;
+            }
+        } else {
+            for (int j = op.from; j < n; j++) {
+                double *p = &T[(size_t)j * ldt + k2];
+                double sum = p[0] + v2 * p[1];
+                p[0] -= sum * t1; p[1] -= sum * t2;
+            }
+        }
+    }
+    void run(int which) {
+        OpRing &r = ring[which];
+        for (;;) {
+            {   // parked between sessions
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return session || quit; });
+                if (quit) return;
+            }
+            unsigned idle = 0;
+            for (;;) {
+                unsigned t = r.tail.load(std::memory_order_relaxed);
+                if (t != r.head.load(std::memory_order_acquire)) {
+                    ReflOp const op = r.ops[t % OpRing::CAP];
+                    if (which == 0) apply_z(job[0], op); else apply_left(job[1], op);
+                    r.tail.store(t + 1, std::memory_order_release);
+                    idle = 0;
+                } else {
+                    _mm_pause();
+                    if (++idle > 4096) {
+                        idle = 0;
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (!session) break;
+                    }
+                }
+            }
+        }
+    }
+    void open() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) { th[0] = std::thread([this] { run(0); }); th[1] = std::thread([this] { run(1); }); started = true; }
+        session = true;
+        cv.notify_all();
+    }
+    void close() { std::lock_guard<std::mutex> lk(mu); session = false; }
+    ~Helpers() {
+        if (!started) return;
+        { std::lock_guard<std::mutex> lk(mu); quit = true; session = false; }
+        cv.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
+    }
+};
+
+Helpers &helpers() { static Helpers h; return h; }
+bool g_helpers_on = false;
+
+} // namespace
+
+// Opens / closes a helper session (schur_device brackets a reduction with it when the node has
+// at least 3 cores; tests switch it on to compare against the serial kernels bit for bit).
+void helper_session(bool on)
+{
+    if (on == g_helpers_on) return;
+    if (on) helpers().open(); else helpers().close();
+    g_helpers_on = on;
+}
 
 static inline double sign(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::fabs(a); }
 
@@ -112,6 +259,15 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
     const int itmax = 30 * std::max(10, n), kexsh = 10;
     if (n == 0) return 0;
     for (int j = 0; j + 2 < n; j++) { T_(j + 2, j) = 0.0; if (j + 3 < n) T_(j + 3, j) = 0.0; }
+    // with helpers: Z and the converged columns of T are updated by two other threads (see above)
+    bool const piped = g_helpers_on && n >= 48;
+    OpRing *qz = nullptr, *ql = nullptr;
+    if (piped) {
+        Helpers &h = helpers();
+        h.job[0] = Job{Z, ldz, n}; h.job[1] = Job{T, ldt, n};
+        qz = &h.ring[0]; ql = &h.ring[1];
+    }
+    struct Drain { OpRing *a, *b; ~Drain() { if (a) a->wait_empty(); if (b) b->wait_empty(); } } drain{qz, ql};
 
     int i = n - 1;
     while (i >= 0) {
@@ -189,9 +345,16 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                 if (k2 > m) { T_(k2, k2 - 1) = v[0]; T_(k2 + 1, k2 - 1) = 0.0; if (k2 < i - 1) T_(k2 + 2, k2 - 1) = 0.0; }
                 else if (m > l) T_(k2, k2 - 1) *= (1.0 - t1);
                 double v2 = v[1], t2 = t1 * v2;
+                // the parts the chain never reads again: on the helper threads, or (the SAME code) here
+                {
+                    ReflOp const op{k2, nr, i + 1, 0, v2, nr == 3 ? v[2] : 0.0, t1};
+                    if (piped) { ql->push(op); qz->push(op); }
+                    else { Helpers::apply_left(Job{T, ldt, n}, op); Helpers::apply_z(Job{Z, ldz, n}, op); }
+                }
+                int const jend = i + 1;                     // left update here: the active block only
                 if (nr == 3) {
                     double v3 = v[2], t3 = t1 * v3;
-                    for (int j = k2; j < n; j++) {
+                    for (int j = k2; j < jend; j++) {
                         double sum = T_(k2, j) + v2 * T_(k2 + 1, j) + v3 * T_(k2 + 2, j);
                         T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2; T_(k2 + 2, j) -= sum * t3;
                     }
@@ -202,14 +365,9 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                             double sum = c0[j] + v2 * c1[j] + v3 * c2[j];
                             c0[j] -= sum * t1; c1[j] -= sum * t2; c2[j] -= sum * t3;
                         }
-                        double *__restrict__ z0 = &Z_(0, k2), *__restrict__ z1 = &Z_(0, k2 + 1), *__restrict__ z2 = &Z_(0, k2 + 2);
-                        for (int j = 0; j < n; j++) {
-                            double sum = z0[j] + v2 * z1[j] + v3 * z2[j];
-                            z0[j] -= sum * t1; z1[j] -= sum * t2; z2[j] -= sum * t3;
-                        }
                     }
                 } else {
-                    for (int j = k2; j < n; j++) {
+                    for (int j = k2; j < jend; j++) {
                         double sum = T_(k2, j) + v2 * T_(k2 + 1, j);
                         T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2;
                     }
@@ -217,11 +375,6 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                     for (int j = 0; j <= i; j++) {
                         double sum = c0[j] + v2 * c1[j];
                         c0[j] -= sum * t1; c1[j] -= sum * t2;
-                    }
-                    double *__restrict__ z0 = &Z_(0, k2), *__restrict__ z1 = &Z_(0, k2 + 1);
-                    for (int j = 0; j < n; j++) {
-                        double sum = z0[j] + v2 * z1[j];
-                        z0[j] -= sum * t1; z1[j] -= sum * t2;
                     }
                 }
             }
@@ -232,9 +385,12 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
             double cs, sn;
             lanv2(T_(i - 1, i - 1), T_(i - 1, i), T_(i, i - 1), T_(i, i),
                 wr[i - 1], wi[i - 1], wr[i], wi[i], cs, sn);
-            rot_rows(T, ldt, i - 1, i, i + 1, n, cs, sn);
+            {
+                ReflOp const op{i - 1, 2, i + 1, 1, cs, sn, 0.0};
+                if (piped) { ql->push(op); qz->push(op); }
+                else { Helpers::apply_left(Job{T, ldt, n}, op); Helpers::apply_z(Job{Z, ldz, n}, op); }
+            }
             rot_cols(T, ldt, i - 1, i, 0, i - 1, cs, sn);
-            rot_cols(Z, ldz, i - 1, i, 0, n, cs, sn);
         }
         i = l - 1;
     }
@@ -690,6 +846,8 @@ int sn_internal_small_schur(int n, double *T, int ldt, double *Z, int ldz, doubl
 __attribute__((visibility("default")))
 int sn_internal_move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
 { return sn::host::move_block_up(n, T, ldt, Z, ldz, from, to); }
+__attribute__((visibility("default")))
+void sn_internal_helper_session(int on) { sn::host::helper_session(on != 0); }
 __attribute__((visibility("default")))
 int sn_internal_deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,
     double thres, int carried, int *undeflated)

@@ -154,3 +154,35 @@ def test_reorder_window_moves_selected_blocks_to_the_top(n, seed):
     assert np.abs(got - exp).max() <= 1e5 * U * np.abs(exp).max()
     # and nothing selected is left below
     assert np.all(np.array(er[placed:]) <= np.median(wr) + 1e5 * U * np.abs(wr).max())
+
+
+@pytest.mark.parametrize("n", [48, 97, 160, 300])
+def test_helper_threads_reproduce_the_serial_kernels_bit_for_bit(n):
+    """small_schur / aed_window with the Z accumulation and the left updates of the converged
+    columns handed to two helper threads (schur_host.hip, `Helpers`): every entry sees the same
+    operations in the same order, so T, Z and the eigenvalues equal the serial results exactly."""
+    L = lib()
+    L.sn_internal_helper_session.argtypes = [C.c_int]
+    H0 = hess_input(n, seed=11)
+    out = []
+    for on in (0, 1, 1, 0):
+        L.sn_internal_helper_session(on)
+        T = H0.copy(order="F"); Z = np.asfortranarray(np.eye(n))
+        wr = np.zeros(n); wi = np.zeros(n)
+        assert L.sn_internal_small_schur(n, P(T), n, P(Z), n, P(wr), P(wi)) == 0
+        out.append((T, Z, wr, wi))
+    L.sn_internal_helper_session(0)
+    for T, Z, wr, wi in out[1:]:
+        assert np.array_equal(T, out[0][0]) and np.array_equal(Z, out[0][1])
+        assert np.array_equal(wr, out[0][2]) and np.array_equal(wi, out[0][3])
+    # the AED window kernel on top of it
+    res = []
+    for on in (0, 1):
+        L.sn_internal_helper_session(on)
+        T = H0.copy(order="F"); Z = np.asfortranarray(np.zeros((n, n)))
+        spike = np.zeros(n); sr = np.zeros(n); si = np.zeros(n); o3 = (C.c_int * 3)()
+        L.sn_internal_aed_window(n, P(T), n, P(Z), n, 0.37, 1e-13 * np.linalg.norm(H0), P(spike), P(sr), P(si), o3)
+        res.append((T, Z, spike, tuple(o3)))
+    L.sn_internal_helper_session(0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
