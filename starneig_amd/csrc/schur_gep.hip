@@ -145,12 +145,14 @@ void gep_chase_kernel(SweepStep const step, double *__restrict__ Ag, int ldA,
                 double const *b = WB + row0 * GLD + row0;
                 double const p0 = b[1], p1 = b[GLD + 1], p2 = b[2 * GLD + 1];       // row row0+1
                 double const q0 = b[2], q1 = b[GLD + 2], q2 = b[2 * GLD + 2];       // row row0+2
-                // scale the rows first: the cross product of two tiny rows would underflow
+                // scale the rows first (by powers of two: exact): the cross product of two tiny rows
+                // would underflow
                 double const mp = fmax(fabs(p0), fmax(fabs(p1), fabs(p2)));
                 double const mq = fmax(fabs(q0), fmax(fabs(q1), fabs(q2)));
                 if (mp > 0.0 && mq > 0.0) {
-                    double const a0 = p0 / mp, a1 = p1 / mp, a2 = p2 / mp;
-                    double const c0 = q0 / mq, c1 = q1 / mq, c2 = q2 / mq;
+                    int const ep = -ilogb(mp), eq = -ilogb(mq);
+                    double const a0 = scalbn(p0, ep), a1 = scalbn(p1, ep), a2 = scalbn(p2, ep);
+                    double const c0 = scalbn(q0, eq), c1 = scalbn(q1, eq), c2 = scalbn(q2, eq);
                     double x[3] = {a1 * c2 - a2 * c1, a2 * c0 - a0 * c2, a0 * c1 - a1 * c0};
                     small_reflector(3, x, beta, w1, w2, tauz);
                 } else if (mp > 0.0) {

@@ -35,6 +35,67 @@ namespace sn { namespace host {
 // The helpers exist only while a session is open (one Schur reduction) and `cores` >= 3.
 namespace {
 
+// Row operations on a column-major matrix touch 2-3 adjacent entries of every column: the loops
+// cannot vectorise, and without help the compiler serialises them (a store to column j might
+// alias the load of column j+1 for all it knows).  Four columns are loaded before any is stored.
+static inline void rows3_reflect(double *T, int ldt, int k2, int j0, int j1, double v2, double v3, double t1)
+{
+    double const t2 = t1 * v2, t3 = t1 * v3;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        double *p0 = T + (size_t)j * ldt + k2, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
+        double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        double c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
+        double sa = a0 + v2 * a1 + v3 * a2, sb = b0 + v2 * b1 + v3 * b2;
+        double sc = c0 + v2 * c1 + v3 * c2, sd = d0 + v2 * d1 + v3 * d2;
+        p0[0] = a0 - sa * t1; p0[1] = a1 - sa * t2; p0[2] = a2 - sa * t3;
+        p1[0] = b0 - sb * t1; p1[1] = b1 - sb * t2; p1[2] = b2 - sb * t3;
+        p2[0] = c0 - sc * t1; p2[1] = c1 - sc * t2; p2[2] = c2 - sc * t3;
+        p3[0] = d0 - sd * t1; p3[1] = d1 - sd * t2; p3[2] = d2 - sd * t3;
+    }
+    for (; j < j1; j++) {
+        double *p = T + (size_t)j * ldt + k2;
+        double a0 = p[0], a1 = p[1], a2 = p[2];
+        double sa = a0 + v2 * a1 + v3 * a2;
+        p[0] = a0 - sa * t1; p[1] = a1 - sa * t2; p[2] = a2 - sa * t3;
+    }
+}
+static inline void rows2_reflect(double *T, int ldt, int k2, int j0, int j1, double v2, double t1)
+{
+    double const t2 = t1 * v2;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        double *p0 = T + (size_t)j * ldt + k2, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
+        double a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
+        double sa = a0 + v2 * a1, sb = b0 + v2 * b1, sc = c0 + v2 * c1, sd = d0 + v2 * d1;
+        p0[0] = a0 - sa * t1; p0[1] = a1 - sa * t2; p1[0] = b0 - sb * t1; p1[1] = b1 - sb * t2;
+        p2[0] = c0 - sc * t1; p2[1] = c1 - sc * t2; p3[0] = d0 - sd * t1; p3[1] = d1 - sd * t2;
+    }
+    for (; j < j1; j++) {
+        double *p = T + (size_t)j * ldt + k2;
+        double a0 = p[0], a1 = p[1], sa = a0 + v2 * a1;
+        p[0] = a0 - sa * t1; p[1] = a1 - sa * t2;
+    }
+}
+// rows r1, r2 (any distance) over columns [c0, c1): x' = cs x + sn y, y' = cs y - sn x
+static inline void rows_rotate(double *T, int ldt, int r1, int r2, int c0, int c1, double cs, double sn)
+{
+    int j = c0;
+    for (; j + 4 <= c1; j += 4) {
+        double *p0 = T + (size_t)j * ldt, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
+        double x0 = p0[r1], y0 = p0[r2], x1 = p1[r1], y1 = p1[r2], x2 = p2[r1], y2 = p2[r2], x3 = p3[r1], y3 = p3[r2];
+        p0[r1] = cs * x0 + sn * y0; p0[r2] = cs * y0 - sn * x0;
+        p1[r1] = cs * x1 + sn * y1; p1[r2] = cs * y1 - sn * x1;
+        p2[r1] = cs * x2 + sn * y2; p2[r2] = cs * y2 - sn * x2;
+        p3[r1] = cs * x3 + sn * y3; p3[r2] = cs * y3 - sn * x3;
+    }
+    for (; j < c1; j++) {
+        double *p = T + (size_t)j * ldt;
+        double x = p[r1], y = p[r2];
+        p[r1] = cs * x + sn * y; p[r2] = cs * y - sn * x;
+    }
+}
+
 struct ReflOp { int k2, nr, from, kind; double a, b, c; };   // kind 0: reflector (v2, v3, t1); 1: rotation (cs, sn)
 
 struct OpRing {
@@ -86,28 +147,9 @@ struct Helpers {
     }
     // T(k2 : k2+nr, from : n) <- G^T .   (columns right of the active block)
     __attribute__((noinline)) static void apply_left(Job const &jb, ReflOp const &op) {
-        double *T = jb.M; int const ldt = jb.ld, n = jb.n, k2 = op.k2;
-        if (op.kind == 1) {
-            for (int j = op.from; j < n; j++) {
-                double x = T[(size_t)j * ldt + k2], y = T[(size_t)j * ldt + k2 + 1];
-                T[(size_t)j * ldt + k2] = op.a * x + op.b * y; T[(size_t)j * ldt + k2 + 1] = op.a * y - op.b * x;
-            }
-            return;
-        }
-        double const v2 = op.a, v3 = op.b, t1 = op.c, t2 = t1 * v2, t3 = t1 * v3;
-        if (op.nr == 3) {
-            for (int j = op.from; j < n; j++) {
-                double *p = &T[(size_t)j * ldt + k2];
-                double sum = p[0] + v2 * p[1] + v3 * p[2];
-                p[0] -= sum * t1; p[1] -= sum * t2; p[2] -= sum * t3;
-            }
-        } else {
-            for (int j = op.from; j < n; j++) {
-                double *p = &T[(size_t)j * ldt + k2];
-                double sum = p[0] + v2 * p[1];
-                p[0] -= sum * t1; p[1] -= sum * t2;
-            }
-        }
+        if (op.kind == 1) rows_rotate(jb.M, jb.ld, op.k2, op.k2 + 1, op.from, jb.n, op.a, op.b);
+        else if (op.nr == 3) rows3_reflect(jb.M, jb.ld, op.k2, op.from, jb.n, op.a, op.b, op.c);
+        else rows2_reflect(jb.M, jb.ld, op.k2, op.from, jb.n, op.a, op.c);
     }
     void run(int which) {
         OpRing &r = ring[which];
@@ -237,10 +279,7 @@ static double house(int n, double *x)
 // rotate rows r1, r2 of T over columns [c0, c1): x' = cs x + sn y, y' = cs y - sn x
 static void rot_rows(double *T, int ldt, int r1, int r2, int c0, int c1, double cs, double sn)
 {
-    for (int j = c0; j < c1; j++) {
-        double x = T_(r1, j), y = T_(r2, j);
-        T_(r1, j) = cs * x + sn * y; T_(r2, j) = cs * y - sn * x;
-    }
+    rows_rotate(T, ldt, r1, r2, c0, c1, cs, sn);
 }
 static void rot_cols(double *T, int ldt, int c1, int c2, int r0, int r1, double cs, double sn)
 {
@@ -354,10 +393,7 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                 int const jend = i + 1;                     // left update here: the active block only
                 if (nr == 3) {
                     double v3 = v[2], t3 = t1 * v3;
-                    for (int j = k2; j < jend; j++) {
-                        double sum = T_(k2, j) + v2 * T_(k2 + 1, j) + v3 * T_(k2 + 2, j);
-                        T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2; T_(k2 + 2, j) -= sum * t3;
-                    }
+                    rows3_reflect(T, ldt, k2, k2, jend, v2, v3, t1);
                     int je = std::min(k2 + 3, i);
                     {   // three distinct columns: restrict-qualified so that the loops vectorise
                         double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1), *__restrict__ c2 = &T_(0, k2 + 2);
@@ -367,10 +403,7 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                         }
                     }
                 } else {
-                    for (int j = k2; j < jend; j++) {
-                        double sum = T_(k2, j) + v2 * T_(k2 + 1, j);
-                        T_(k2, j) -= sum * t1; T_(k2 + 1, j) -= sum * t2;
-                    }
+                    rows2_reflect(T, ldt, k2, k2, jend, v2, t1);
                     double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1);
                     for (int j = 0; j <= i; j++) {
                         double sum = c0[j] + v2 * c1[j];
