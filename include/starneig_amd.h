@@ -90,6 +90,13 @@ starneig_error_t starneig_amd_gep_schur_device(
     double *real, double *imag, double *beta,
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
+/* Device-resident twin of starneig_GEP_SM_HessenbergTriangular (wrappers/lapack.c:45-176):
+ * general (dA, dB) -> (H, T); dQ / dZ may be NULL.  stats (may be NULL, double[8]): [0] total ms,
+ * [1] QR step ms, [2] rotation step ms, [3] executed GEMM flops, [4] rotations applied. */
+starneig_error_t starneig_amd_hessenberg_triangular_device(
+    int n, double *dA, int ldA, double *dB, int ldB, double *dQ, int ldQ, double *dZ, int ldZ,
+    void *stream, double *stats);
+
 /* fp64 MFMA GEMM, BLAS dgemm semantics on device pointers (the kernel behind
  * rows H4-H8 and S3; replaces cblas_dgemm/cublasDgemm call sites). */
 starneig_error_t starneig_amd_dgemm_device(

@@ -55,6 +55,13 @@ def lib():
         L.oracle_gep_extract_eigenvalues.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, dp, dp]
         L.oracle_check_gep_schur_form.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int]
         L.oracle_check_gep_schur_form.restype = C.c_int
+        L.oracle_ht_qr.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int]
+        L.oracle_ht_qr.restype = C.c_int
+        L.oracle_ht_reduce.argtypes = [C.c_int] + [dp, C.c_int] * 4
+        L.oracle_ht_reduce.restype = C.c_int
+        L.oracle_hessenberg_triangular.argtypes = [C.c_int] + [dp, C.c_int] * 4
+        L.oracle_hessenberg_triangular.restype = C.c_int
+        L.oracle_lartg.argtypes = [C.c_double, C.c_double, dp, dp, dp]
         _LIB = L
     return _LIB
 
@@ -217,3 +224,51 @@ def match_eigenvalues(ev_a, ev_b):
         worst = max(worst, d[k] / max(abs(x), 1e-3 * scale))
         b.pop(k)
     return worst / 2.0 ** -52
+
+
+def random_fullpos_pair(n, seed=2019, ld=None):
+    """The test driver's generalized Hessenberg input: A, then B, both generate_random_fullpos
+    on one LCG stream (test/hessenberg/experiment.c:102-106)."""
+    ld = ld or ld_for(n)
+    A = np.zeros((ld, n), order="F")
+    B = np.zeros((ld, n), order="F")
+    lib().oracle_init_prand(seed)
+    lib().oracle_fill_random_fullpos(n, n, _p(A), ld)
+    lib().oracle_fill_random_fullpos(n, n, _p(B), ld)
+    return A, B
+
+
+def ht_qr(A, B, Q):
+    """B = Q0 R; A <- Q0^T A; Q <- Q Q0; B <- R (wrappers/lapack.c:143-160). In place."""
+    n = A.shape[1]
+    rc = lib().oracle_ht_qr(n, _p(A), A.shape[0], _p(B), B.shape[0], _p(Q), Q.shape[0])
+    assert rc == 0
+    return A, B, Q
+
+
+def ht_reduce(A, B, Q, Z):
+    """dgghrd-ordered rotations on (A, triangular B). In place."""
+    n = A.shape[1]
+    rc = lib().oracle_ht_reduce(n, _p(A), A.shape[0], _p(B), B.shape[0], _p(Q), Q.shape[0], _p(Z), Z.shape[0])
+    assert rc == 0
+    return A, B, Q, Z
+
+
+def hessenberg_triangular(A, B, Q, Z):
+    """starneig_GEP_SM_HessenbergTriangular restated (wrappers/lapack.c:45-176). In place."""
+    n = A.shape[1]
+    rc = lib().oracle_hessenberg_triangular(n, _p(A), A.shape[0], _p(B), B.shape[0], _p(Q), Q.shape[0],
+                                            _p(Z), Z.shape[0])
+    assert rc == 0
+    return A, B, Q, Z
+
+
+def lartg(f, g):
+    c, s, r = C.c_double(), C.c_double(), C.c_double()
+    lib().oracle_lartg(f, g, C.byref(c), C.byref(s), C.byref(r))
+    return c.value, s.value, r.value
+
+
+def count_below_diagonal(T):
+    n = T.shape[1]
+    return int(np.count_nonzero(np.tril(T[:n, :n], -1)))

@@ -115,6 +115,7 @@ SN_API void starneig_node_finalize(void)
     sn::schur_release_workspace();
     sn::gep_schur_release_workspace();
     sn::reorder_release_workspace();
+    sn::hessenberg_triangular_release_workspace();
     g_node.initialized = false;
 }
 
@@ -139,6 +140,7 @@ SN_API void starneig_amd_release_workspace(void)
     sn::hessenberg_release_workspace();
     sn::schur_release_workspace();
     sn::gep_schur_release_workspace();
+    sn::hessenberg_triangular_release_workspace();
 }
 
 // ---- host-array interface (in place, like the reference) ----------------------
@@ -542,6 +544,86 @@ SN_API starneig_error_t starneig_GEP_SM_Schur(
     if (ldZ < n)    return -9;           // schur/interface.c:286-294: nothing beyond -9
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     return starneig_GEP_SM_Schur_expert(NULL, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta);
+}
+
+// ---- Hessenberg-triangular reduction (gep_sm.h; wrappers/lapack.c:45-176) --------------
+SN_API starneig_error_t starneig_GEP_SM_HessenbergTriangular(
+    int n, double A[], int ldA, double B[], int ldB, double Q[], int ldQ, double Z[], int ldZ)
+{
+    if (n < 1)      return -1;
+    if (A == NULL)  return -2;
+    if (ldA < n)    return -3;
+    if (B == NULL)  return -4;
+    if (ldB < n)    return -5;
+    if (Q == NULL)  return -6;
+    if (ldQ < n)    return -7;
+    if (Z == NULL)  return -8;
+    if (ldZ < n)    return -9;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+
+    int const ld = (int)sn::roundup(n, 16);
+    size_t const bytes = (size_t)ld * n * sizeof(double);
+    double *host[4] = {A, B, Q, Z};
+    int const lds[4] = {ldA, ldB, ldQ, ldZ};
+    double *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        SN_HIP_CHECK(hipMalloc((void **)&dev[i], bytes));
+        SN_HIP_CHECK(hipMemset(dev[i], 0, bytes));
+        SN_HIP_CHECK(hipMemcpy2D(dev[i], (size_t)ld * 8, host[i], (size_t)lds[i] * 8, (size_t)n * 8, n,
+            hipMemcpyHostToDevice));
+    }
+    int const rc = sn::hessenberg_triangular_device(nullptr, n, dev[0], ld, dev[1], ld, dev[2], ld, dev[3], ld, nullptr);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < 4; i++) {
+        SN_HIP_CHECK(hipMemcpy2D(host[i], (size_t)lds[i] * 8, dev[i], (size_t)ld * 8, (size_t)n * 8, n,
+            hipMemcpyDeviceToHost));
+        SN_HIP_CHECK(hipFree(dev[i]));
+    }
+    return rc;
+}
+
+// common/combined.c:98-153: HessenbergTriangular + Schur (+ Select + ReorderSchur with a predicate;
+// the generalized reordering is not on this path, a predicate is refused)
+SN_API starneig_error_t starneig_GEP_SM_Reduce(
+    int n, double A[], int ldA, double B[], int ldB, double Q[], int ldQ, double Z[], int ldZ,
+    double real[], double imag[], double beta[],
+    int (*predicate)(double real, double imag, double beta, void *arg), void *arg,
+    int selected[], int *num_selected)
+{
+    if (n < 1)      return -1;
+    if (A == NULL)  return -2;
+    if (ldA < n)    return -3;
+    if (B == NULL)  return -4;
+    if (ldB < n)    return -5;
+    if (Q == NULL)  return -6;
+    if (ldQ < n)    return -7;
+    if (Z == NULL)  return -8;
+    if (ldZ < n)    return -9;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    if (predicate) {
+        (void)arg; (void)selected; (void)num_selected;
+        fprintf(stderr, "[starneig-amd] starneig_GEP_SM_Reduce: the generalized ReorderSchur step is not "
+            "part of this library; call without a predicate.\n");
+        return STARNEIG_GENERIC_ERROR;
+    }
+    int rc = starneig_GEP_SM_HessenbergTriangular(n, A, ldA, B, ldB, Q, ldQ, Z, ldZ);
+    if (rc != STARNEIG_SUCCESS) return rc;
+    return starneig_GEP_SM_Schur(n, A, ldA, B, ldB, Q, ldQ, Z, ldZ, real, imag, beta);
+}
+
+SN_API starneig_error_t starneig_amd_hessenberg_triangular_device(
+    int n, double *dA, int ldA, double *dB, int ldB, double *dQ, int ldQ, double *dZ, int ldZ,
+    void *stream, double *stats)
+{
+    if (n < 1)                 return -1;
+    if (dA == NULL)            return -2;
+    if (ldA < n)               return -3;
+    if (dB == NULL)            return -4;
+    if (ldB < n)               return -5;
+    if (dQ != NULL && ldQ < n) return -7;
+    if (dZ != NULL && ldZ < n) return -9;
+    if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
+    return sn::hessenberg_triangular_device((hipStream_t)stream, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, stats);
 }
 
 // ---- device-pointer extension -------------------------------------------------

@@ -121,5 +121,9 @@ int gep_schur_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int 
     SchurParams const &params, SchurStats *stats);
 void gep_schur_release_workspace();
 void lcg_pencil(hipStream_t s, int n, unsigned seed, double *H, int ldh, double *R, int ldr);
+// Hessenberg-triangular reduction (hess_tri.hip): general (dA, dB) -> (H, T), dQ <- dQ*U1, dZ <- dZ*U2
+int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,
+    double *dQ, int ldQ, double *dZ, int ldZ, double *stats);
+void hessenberg_triangular_release_workspace();
 
 } // namespace sn

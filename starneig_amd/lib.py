@@ -85,6 +85,13 @@ SIGNATURES = {
     "starneig_GEP_SM_Schur_expert": (
         C.c_int, [C.POINTER(SchurConf), C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp,
                   C.c_int, _vp, _vp, _vp]),
+    "starneig_GEP_SM_HessenbergTriangular": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int]),
+    "starneig_GEP_SM_Reduce": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
+                  _vp, _vp, _vp, _vp]),
+    "starneig_amd_hessenberg_triangular_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
     "starneig_amd_gep_schur_device": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
                   C.POINTER(SchurConf), _vp, _dp]),
@@ -206,6 +213,19 @@ def GEP_SM_Schur(n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta):
     return load().starneig_GEP_SM_Schur(
         n, _host_ptr(H), ldH, _host_ptr(R), ldR, _host_ptr(Q), ldQ, _host_ptr(Z), ldZ,
         _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta))
+
+
+def GEP_SM_HessenbergTriangular(n, A, ldA, B, ldB, Q, ldQ, Z, ldZ):
+    """reference gep_sm.h:106-111 (wrappers/lapack.c:45-176)."""
+    return load().starneig_GEP_SM_HessenbergTriangular(
+        n, _host_ptr(A), ldA, _host_ptr(B), ldB, _host_ptr(Q), ldQ, _host_ptr(Z), ldZ)
+
+
+def GEP_SM_Reduce(n, A, ldA, B, ldB, Q, ldQ, Z, ldZ, real, imag, beta):
+    """reference gep_sm.h:316-326 without a predicate: HessenbergTriangular + Schur."""
+    return load().starneig_GEP_SM_Reduce(
+        n, _host_ptr(A), ldA, _host_ptr(B), ldB, _host_ptr(Q), ldQ, _host_ptr(Z), ldZ,
+        _arr_ptr(real), _arr_ptr(imag), _arr_ptr(beta), None, None, None, None)
 
 
 def GEP_SM_Schur_expert(conf, n, H, ldH, R, ldR, Q, ldQ, Z, ldZ, real, imag, beta):
@@ -354,6 +374,18 @@ def reorder_schur_device(tS, tQ, selected, n=None, conf=None, eigenvalues=True):
         tQ.shape[1] if tQ is not None else 0, _arr_ptr(real), _arr_ptr(imag),
         C.byref(conf) if conf is not None else None, _stream_ptr(), st)
     return rc, real, imag, {"windows": int(st[0]), "gemm_flops": st[1]}
+
+
+def hessenberg_triangular_device(tA, tB, tQ, tZ, n=None):
+    """Device-resident Hessenberg-triangular reduction. Returns (rc, stats)."""
+    n = tA.shape[0] if n is None else n
+    st = (C.c_double * 8)()
+    rc = load().starneig_amd_hessenberg_triangular_device(
+        n, _dev_ptr(tA), tA.shape[1], _dev_ptr(tB), tB.shape[1],
+        _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0,
+        _dev_ptr(tZ), tZ.shape[1] if tZ is not None else 0, _stream_ptr(), st)
+    return rc, {"total_ms": st[0], "qr_ms": st[1], "rotation_ms": st[2], "gemm_flops": st[3],
+                "rotations": st[4]}
 
 
 def gep_schur_device(tH, tR, tQ, tZ, n=None, conf=None, eigenvalues=True):
