@@ -148,25 +148,24 @@ __device__ inline double readlane_d(double v, int l)
     return __hiloint2double(hi, lo);
 }
 
-// LAPACK >= 3.10 dlartg: [c s; -s c] (f, g)^T = (r, 0)^T, c >= 0, r carries the sign of f.
-// On the chain every dependent instruction counts, and a branch on a fresh VALU result costs as much
-// as ten of them (measured: 66 ns for LAPACK's safe-range test): 1/sqrt(f^2+g^2) from v_rsq_f64 and
-// two Newton steps (no division, no sqrt expansion), the special cases as selects.  Range: B is
-// scaled to max|b| in [1, 2) for the rotation step (hessenberg_triangular_device), rotations preserve
-// the Frobenius norm, so f^2 + g^2 cannot overflow; where it underflows (both below 1e-140 of the
-// largest entry) the fill-in is dropped, a backward error far below u.
-__device__ inline void ht_lartg(double f, double g, double &c, double &s, double &r)
+// LAPACK >= 3.10 dlartg conventions: [c s; -s c] (f, g)^T = (r, 0)^T, c >= 0, r = c f + s g carries the
+// sign of f.  On the chain every instruction counts (a wave64 VALU instruction occupies the SIMD
+// for 4 cycles, a dependent fp64 result takes 6) and a branch on a fresh VALU result costs as much as
+// ten of them (measured: 66 ns for LAPACK's safe-range test): 1/sqrt(f^2+g^2) from v_rsq_f64
+// (2^-24) and ONE third-order Newton step (measured residual 1.6e-16 over the range), no division,
+// no sqrt expansion, one select.  Range: B is scaled to max|b| in [1, 2) on entry
+// (hessenberg_triangular_device), rotations preserve the Frobenius norm, so f^2 + g^2 cannot
+// overflow; where it underflows (both below 1e-140 of the largest entry) the fill-in is dropped, a
+// backward error far below u.
+__device__ inline void ht_lartg(double f, double g, double &c, double &s)
 {
     double const h2 = fma(f, f, g * g);
     double y = __builtin_amdgcn_rsq(h2);
-    double e1 = fma(-h2 * y, y, 1.0);
+    double const e1 = fma(-h2 * y, y, 1.0);
     y = fma(y * e1, fma(0.375, e1, 0.5), y);            // y (1 + e/2 + 3 e^2 / 8)
-    e1 = fma(-h2 * y, y, 1.0);
-    y = fma(y * 0.5, e1, y);
-    bool const trivial = g == 0.0 || h2 < 1e-280;       // also covers f = g = 0 (y = inf)
+    bool const trivial = h2 < 1e-280;                   // also f = g = 0 (y = inf)
     c = trivial ? 1.0 : fabs(f) * y;
     s = trivial ? 0.0 : g * copysign(y, f);
-    r = trivial ? f : copysign(h2 * y, f);
 }
 
 // All row rotations of sweep j from column j of A: rotation i (rows i-1, i), i = n-1 .. j+2, is
@@ -425,7 +424,7 @@ __device__ inline void ht_wait(unsigned ctr, int which, int need)
 {
     int spins = 0;
     while (lds_load(ctr + 4 * which) < need && lds_load(ctr + 12) == 0) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 21)) lds_store(ctr + 12, 1);
     }
 }
@@ -451,7 +450,6 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
     __shared__ double rot[64 * G][2];                                   // (c, s) of rotation t at t_hi - t
     __shared__ int ctr_words[4];                                        // 0: rotations published, 1: tiles loaded, 2: blocks finished, 3: abort
     unsigned const ctr = lds_addr(ctr_words);
-    __shared__ double sink[128 + 64];                                   // where idle lanes store
     int const wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int const t_hi = g1 - 1, t_lo = std::max(g0, j + 2);
     int const wtop = std::min(G - 1, (t_hi - g0) / 64), wbot = (t_lo - g0) / 64;
@@ -571,7 +569,7 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
     // waits: per rotation one LDS read (next column, consumed one iteration later) and three
     // writes (rotation, result column, counter) that nothing on the chain waits for.  The fill-ins
     // B(t, t-1) -- the tile's diagonal -- are read once into lane t of a register and cleared at the end.
-    unsigned const a_tile = lds_addr(&tl[0][0]), a_rot = lds_addr(&rot[0][0]), a_sink = lds_addr(&sink[0]);
+    unsigned const a_tile = lds_addr(&tl[0][0]), a_rot = lds_addr(&rot[0][0]);
     double fv, xn;                                      // (through asm as well: a compiler-tracked LDS read pending at the
                                                         //  loop header would put an s_waitcnt lgkmcnt(0) inside the loop)
     asm volatile("ds_read_b64 %0, %1" : "=v"(fv) : "v"(a_tile + 8u * 65u * lane) : "memory");
@@ -584,22 +582,43 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(x) :: "memory");            // the three writes behind the read may stay in flight
         asm volatile("ds_read_b64 %0, %1" : "=v"(xn) : "v"(a_tile + 8u * (64u * std::max(q - 1, q_lo) + lane)) : "memory");
         double const d = readlane_d(y, q), f = readlane_d(fv, q);
-        double c, s, r;
-        ht_lartg(d, f, c, s, r);
-        double const yf = s * x + c * y, yc = c * x - s * y;
-        // stores without a branch: lanes that have nothing to write aim at a scratch row of LDS
-        // (an `if` around a store is a compare, an exec save and a branch on the chain: 80 ns measured)
-        double const res = (lane < q) ? yf : r;                                 // column t, final
-        asm volatile("ds_write_b128 %0, %1" :: "v"(lane == 0 ? a_rot + 16u * (t_hi - t) : a_sink + 16u * lane), "v"(v2d{c, s}) : "memory");
-        asm volatile("ds_write_b64 %0, %1" :: "v"(lane <= q ? a_tile + 8u * (64u * (q + 1) + lane) : a_sink + 8u * lane), "v"(res) : "memory");
+        double c, s;
+        ht_lartg(d, f, c, s);
+        // No select anywhere: in the pivot lane x = f and y = d, so s x + c y IS r; the lanes past the
+        // pivot (rows below t) compute and store values that nobody reads -- the loader writes back
+        // rows <= t only -- and an `if` around a store would be a compare, an exec save and a branch
+        // on the chain (80 ns measured).
+        double const yf = s * x + c * y;                                        // column t, final
+        y = c * x - s * y;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(a_rot + 16u * (t_hi - t)), "v"(v2d{c, s}) : "memory");
+        asm volatile("ds_write_b64 %0, %1" :: "v"(a_tile + 8u * (64u * (q + 1) + lane)), "v"(yf) : "memory");
         asm volatile("ds_write_b32 %0, %1" :: "v"(ctr), "v"(t_hi - t + 1) : "memory");   // published: the LDS queue keeps the order
-        y = (lane < q) ? yc : (lane == q ? 0.0 : y);
         if ((DBG & 32) && ts && lane == 0 && (t % CH == 0 || q == q_lo)) ts[(t_hi - t) / CH] = wall_clock64();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane >= q_lo && lane <= q_hi) tl[lane][lane] = 0.0;                     // the removed fill-ins
     lds_store(ctr + 8, k + 1);
     if (rv && row < t_lo) B[(size_t)(t_lo - 1) * ldb + row] = y;
+}
+
+// max |b_ij|, as the bit pattern of a non-negative double (ordered like integers)
+__global__ __launch_bounds__(256) void ht_absmax_kernel(int n, double const *__restrict__ B, int ldb, unsigned long long *out)
+{
+    int const c = blockIdx.y;
+    double m = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmax(m, fabs(B[(size_t)c * ldb + i]));
+    for (int o = 32; o; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
+// B <- B * 2^(-dir * e), e = exponent of the largest entry: exact; the sums of squares of the QR step
+// and of the chain then stay in range without LAPACK's rescaling branches
+__global__ __launch_bounds__(256) void ht_scale_kernel(int n, double *__restrict__ B, int ldb, unsigned long long const *amax, int dir)
+{
+    int const c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    double const m = __longlong_as_double((long long)*amax);
+    if (i >= n || m == 0.0 || !(m < 1.7e308)) return;
+    B[(size_t)c * ldb + i] = scalbn(B[(size_t)c * ldb + i], -dir * ilogb(m));
 }
 
 __global__ void ht_clear_lower_kernel(int n, double *__restrict__ B, int ldb)
@@ -613,6 +632,7 @@ struct HtWorkspace {
     double *Vp = nullptr, *VT = nullptr, *W = nullptr, *G = nullptr, *T = nullptr, *tau = nullptr;
     double *part[2] = {nullptr, nullptr}, *prow[2] = {nullptr, nullptr};
     double *Rc2[2] = {nullptr, nullptr}, *Rs2[2] = {nullptr, nullptr}, *Rc = nullptr, *Rs = nullptr, *Cc = nullptr, *Cs = nullptr;
+    unsigned long long *amax = nullptr;
     double *rp_beta[2] = {nullptr, nullptr}, *rp_up[2] = {nullptr, nullptr}, *rp_alpha[2] = {nullptr, nullptr};   // row pass: [0] B, [1] A
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipStream_t side = nullptr, qstream = nullptr;
@@ -646,6 +666,7 @@ struct HtWorkspace {
         for (int b = 0; b < 2; b++) { alloc(part[b], (size_t)divceil(n, QROWS) * QP); alloc(prow[b], QNB); }
         for (int b = 0; b < 2; b++) { alloc(Rc2[b], n); alloc(Rs2[b], n); }
         alloc(Cc, n); alloc(Cs, n);
+        if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 8));
         for (int b = 0; b < 2; b++) {
             alloc(rp_beta[b], (size_t)divceil(n, 64) * n); alloc(rp_up[b], (size_t)divceil(n, 64) * n); alloc(rp_alpha[b], divceil(n, 64));
         }
@@ -715,6 +736,9 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     ws.ensure(n);
     double flops = 0.0, rotations = 0.0;
     SN_HIP_CHECK(hipEventRecord(ws.ev[0], s));
+    SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 8, s));
+    hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dB, ldB, ws.amax);
+    hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, 1);
     ht_qr_step(s, ws, n, dA, ldA, dB, ldB, dQ, ldQ, &flops);
     hipLaunchKernelGGL(ht_clear_lower_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB);
     SN_HIP_CHECK(hipEventRecord(ws.ev[1], s));
@@ -765,6 +789,7 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     }
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));
     if (dQ && n > 2) { SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0)); if (n > 3) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0)); }
+    hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, -1);
     SN_HIP_CHECK(hipEventRecord(ws.ev[2], s));
     SN_HIP_CHECK(hipStreamSynchronize(s));
     if (stats) {

@@ -123,6 +123,22 @@ def test_singular_b_and_zero_columns(node):
     assert max(ra, rb, oq, oz) < WARN_U
 
 
+@pytest.mark.parametrize("scale", [2.0 ** -600, 2.0 ** 500, 3.7e-170])
+def test_badly_scaled_b(node, scale):
+    # the chain works on B scaled to max|b| in [1, 2) (exact powers of two): results scale back exactly
+    n = 130
+    A0, B0 = O.random_fullpos_pair(n)
+    H1, T1, Q1, Z1 = run_host(node, A0, B0)
+    Bs = np.asfortranarray(B0 * scale)
+    H2, T2, Q2, Z2 = run_host(node, A0, Bs)
+    check_structure(H2, T2)
+    ra, rb, oq, oz = residuals(A0, Bs, H2, T2, Q2, Z2)
+    assert max(ra, rb, oq, oz) < WARN_U
+    if scale in (2.0 ** -600, 2.0 ** 500):
+        assert np.array_equal(H1, H2) and np.array_equal(Q1, Q2) and np.array_equal(Z1, Z2)
+        assert np.array_equal(T1[:n] * scale, T2[:n])
+
+
 def test_argument_checks(node):
     n = 8
     A0, B0 = O.random_fullpos_pair(n)
