@@ -96,6 +96,86 @@ def bench_qz(args):
     S.node_finalize()
 
 
+def ht_flops(n):
+    # 4/3 n^3 (QR of B) + 2 n^3 (Q0^T A) + 2 n^3 (Q Q0) + 14 n^3 (Moler-Stewart rotations with Q and Z,
+    # Golub & Van Loan): the convention for the reduction the reference delegates to LAPACK
+    return (16.0 / 3.0 + 14.0) * n ** 3
+
+
+def lapack_ht_seconds(n):
+    """dgeqrf + dormqr + dgghd3 (what wrappers/lapack.c calls) and the unblocked dgghrd, on the host
+    cores, through scipy's bundled OpenBLAS; returns (dgghd3 chain s, dgghrd chain s) or None."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from make_golden_ht import lapack_ht, lcg_fullpos_pair
+        import numpy as np
+        rng = np.random.default_rng(2019)
+        A, B = rng.random((n, n)), rng.random((n, n))
+        out = []
+        for blocked in (True, False):
+            t0 = time.perf_counter()
+            lapack_ht(A, B, blocked=blocked)
+            out.append(time.perf_counter() - t0)
+        return out
+    except Exception:
+        return None
+
+
+def bench_ht(args):
+    """Hessenberg-triangular reduction (the step before BASELINE config 5): general
+    pencil from the reference test driver's generator (two LCG matrices), n = 12000 by default,
+    Q = Z = I, device resident.  Not the headline metric; one JSON line of the same shape."""
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import starneig_amd as S
+    S.node_init(1, 1, S.NO_MESSAGES)
+    n = args.n if args.n != 20000 else 12000
+    tA0, tB0 = S.device_matrix(n), S.device_matrix(n)
+    S.lcg_fill_device(tA0, n, n, seed=2019); S.lcg_fill_device(tB0, n, n, seed=77)
+    tQ, tZ = S.device_matrix(n), S.device_matrix(n)
+    times, st = [], None
+    for it in range(args.warmup + args.steps):
+        tA, tB = tA0.clone(), tB0.clone()
+        S.set_matrix_device(tQ, n, n, 0.0, 1.0); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+        torch.cuda.synchronize()
+        assert rc == 0
+        if it >= args.warmup:
+            times.append(time.perf_counter() - t0)
+    _, ca = S.check_pencil_device(tQ, tA, tZ, tA0, n=n)
+    _, cb = S.check_pencil_device(tQ, tB, tZ, tB0, n=n)
+    total = sum(times)
+    cpu = lapack_ht_seconds(args.cpu_ht_n) if args.cpu_ht_n > 0 else None
+    chain_steps = st["rotations"] / 2
+    print(json.dumps({
+        "metric": "GFLOP/s Hessenberg-triangular reduction, n=12000 general pencil, 1 MI355X",
+        "value": args.steps * ht_flops(n) / total / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"Hessenberg-triangular reduction, n={n}, Q and Z accumulated, LCG pencil "
+                               f"(seeds 2019 / 77); value = (16/3 + 14) n^3 flop / time",
+                   "n": n, "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
+                   "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
+                   "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
+                   "qr_step_s": st["qr_ms"] / 1e3, "rotation_step_s": st["rotation_ms"] / 1e3,
+                   "ns_per_chain_rotation": st["rotation_ms"] * 1e6 / max(chain_steps, 1)},
+        # the step is bound by the dependent chain of n^2/2 column rotations, not by a roofline:
+        "roofline": {"bound": "latency", "achieved": st["rotation_ms"] * 1e6 / max(chain_steps, 1),
+                     "peak": 78.0, "unit": "ns per dependent rotation (peak = the bare arithmetic of one "
+                     "rotation on one wave, scratch/ht_micro.hip)", "frac": 78.0 / (st["rotation_ms"] * 1e6 / max(chain_steps, 1)),
+                     "traffic": None},
+        "cpu_baseline": None if cpu is None else {
+            "value": ht_flops(args.cpu_ht_n) / cpu[0] / 1e9, "unit": "GFLOP/s", "cores": os.cpu_count(),
+            "kind": "reference", "sample": f"LAPACK dgeqrf + dormqr + dgghd3 (the calls of wrappers/lapack.c) at "
+            f"n={args.cpu_ht_n}: {cpu[0]:.1f} s; with the unblocked dgghrd: {cpu[1]:.1f} s (scipy's OpenBLAS, all cores)"},
+    }), flush=True)
+    S.node_finalize()
+
+
 def cpu_baseline(n_lapack, n_port):
     """CPU baseline on this host's cores, on bounded samples of the same workload (smaller n,
     same LCG input, same flop conventions):
@@ -260,13 +340,18 @@ def main():
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded Hessenberg path even at N=1 (exercises the collectives)")
-    ap.add_argument("--workload", choices=["sep", "qz"], default="sep",
-                    help="sep = Hessenberg + Schur (the headline metric); qz = BASELINE config 5")
+    ap.add_argument("--workload", choices=["sep", "qz", "ht"], default="sep",
+                    help="sep = Hessenberg + Schur (the headline metric); qz = BASELINE config 5; "
+                         "ht = Hessenberg-triangular reduction (the step before config 5)")
+    ap.add_argument("--cpu-ht-n", type=int, default=1500,
+                    help="size of the LAPACK sample of the ht workload (0 = skip)")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
     if args.workload == "qz":
         return bench_qz(args)
+    if args.workload == "ht":
+        return bench_ht(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 

@@ -352,12 +352,12 @@ __device__ inline double ht_apply_cols(double *__restrict__ M, int ld, int row, 
     CS cs, double sgn, double y)
 {
     int t = t_hi;
-    for (; t - 15 >= t_lo; t -= 16) {
-        double x[16];
+    for (; t - 31 >= t_lo; t -= 32) {
+        double x[32];
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = M[(size_t)(t - k - 1) * ld + row];
+        for (int k = 0; k < 32; k++) x[k] = M[(size_t)(t - k - 1) * ld + row];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < 32; k++) {
             double const c = cs.c(t - k), s = sgn * cs.s(t - k);
             M[(size_t)(t - k) * ld + row] = s * x[k] + c * y;
             y = c * x[k] - s * y;
@@ -773,15 +773,18 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
             int const g0 = std::max(0, (g1 - 1) / HGR * HGR);
             // the rows that enter the followers of this launch were updated last by the side stream's
             // column pass of the previous group
-            if (gi >= 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_rest[gi - 1], 0));
             hipLaunchKernelGGL((ht_chain_kernel<HG, HF>), dim3(1), dim3(64 * (HG + HF + 1)), CHAIN_LDS_DOUBLES(HG) * 8, s, n, j, g0, g1, dB, ldB, ws.Cc, ws.Cs, (long long *)nullptr);
             SN_HIP_CHECK(hipEventRecord(ws.e_chain[gi], s));
             int const t_hi = g1 - 1, t_lo = std::max(g0, j + 2);
             int const near_lo = std::max(0, g0 - 64 * HF);          // rows [near_lo, g0): followers of the chain kernel
+            // the rows of B above the followers: next on the chain's own stream (the next launch needs
+            // them); A and Z: on the side stream, nobody waits for them before the sweep ends
+            if (near_lo > 0)
+                hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(near_lo, 64), 1), dim3(64), 0, s,
+                    ColJob{dB, ldB, near_lo}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
             SN_HIP_CHECK(hipStreamWaitEvent(side, ws.e_chain[gi], 0));
-            hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 3), dim3(64), 0, side,
-                ColJob{dB, ldB, near_lo}, ColJob{dA, ldA, n}, ColJob{dZ, ldZ, dZ ? n : 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
-            SN_HIP_CHECK(hipEventRecord(ws.e_rest[gi], side));
+            hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 2), dim3(64), 0, side,
+                ColJob{dA, ldA, n}, ColJob{dZ, ldZ, dZ ? n : 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
             g1 = g0;
         }
         SN_HIP_CHECK(hipEventRecord(ws.e_side, side));
