@@ -74,7 +74,7 @@ starneig_error_t starneig_amd_schur_rows_device(
  * cuda.cu:126-761 + the GEMM updates of common/cpu.c:54-162): dS <- U^T dS U, dQ <- dQ U (dQ may
  * be NULL).  selected is a HOST array (in: marks of the selected eigenvalues, out: final positions
  * of the placed ones); real/imag HOST arrays (both NULL = not extracted).  conf may be NULL.
- * stats (may be NULL) is double[2]: [0] windows processed, [1] executed GEMM flops. */
+ * stats (may be NULL) is double[4]: [0] windows processed, [1] executed GEMM flops, [2] rounds. */
 struct starneig_reorder_conf;
 starneig_error_t starneig_amd_reorder_schur_device(
     int n, int *selected, double *dS, int ldS, double *dQ, int ldQ, double *real, double *imag,

@@ -20,7 +20,7 @@ void sumsq_diff(hipStream_t s, int m, int n, double const *X, int ldx, double co
 void count_below(hipStream_t s, int n, double const *H, int ldh, double *acc);
 int reorder_schur_device(hipStream_t caller, int n, int *selected, double *dS, int ldS,
     double *dQ, int ldQ, double *real, double *imag, int window_size, int values_per_chain,
-    double *stats);
+    double *stats, int host_threads);
 void reorder_release_workspace();
 }
 
@@ -420,7 +420,7 @@ SN_API starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
     SN_HIP_CHECK(hipMemcpy2D(dS, (size_t)ld * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
     SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
     if (real == NULL || imag == NULL) real = imag = nullptr;
-    rc = sn::reorder_schur_device(nullptr, n, selected, dS, ld, dQ, ld, real, imag, window, vpc, nullptr);
+    rc = sn::reorder_schur_device(nullptr, n, selected, dS, ld, dQ, ld, real, imag, window, vpc, nullptr, g_node.cores);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
     SN_HIP_CHECK(hipMemcpy2D(S, (size_t)ldS * 8, dS, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
     SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
@@ -457,7 +457,7 @@ SN_API starneig_error_t starneig_amd_reorder_schur_device(
     if (rc != STARNEIG_SUCCESS) return rc;
     if (real == NULL || imag == NULL) real = imag = nullptr;
     return sn::reorder_schur_device((hipStream_t)stream, n, selected, dS, ldS, dQ, ldQ, real, imag,
-        window, vpc, stats);
+        window, vpc, stats, g_node.cores);
 }
 
 // common/combined.c:46-98

@@ -368,12 +368,12 @@ def reorder_schur_device(tS, tQ, selected, n=None, conf=None, eigenvalues=True):
     assert selected.dtype == np.int32
     real = np.zeros(n) if eigenvalues else None
     imag = np.zeros(n) if eigenvalues else None
-    st = (C.c_double * 2)()
+    st = (C.c_double * 4)()
     rc = load().starneig_amd_reorder_schur_device(
         n, selected.ctypes.data, _dev_ptr(tS), tS.shape[1], _dev_ptr(tQ),
         tQ.shape[1] if tQ is not None else 0, _arr_ptr(real), _arr_ptr(imag),
         C.byref(conf) if conf is not None else None, _stream_ptr(), st)
-    return rc, real, imag, {"windows": int(st[0]), "gemm_flops": st[1]}
+    return rc, real, imag, {"windows": int(st[0]), "gemm_flops": st[1], "rounds": int(st[2])}
 
 
 def hessenberg_triangular_device(tA, tB, tQ, tZ, n=None):
