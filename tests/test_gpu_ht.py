@@ -75,6 +75,17 @@ def test_qr_step_matches_oracle(node):
     assert np.abs(sv - sv0).max() <= 1e3 * U * sv0[0]
 
 
+@pytest.mark.parametrize("n", [449, 511, 512, 513, 575, 1023, 1025, 1089])
+def test_sizes_around_group_and_block_boundaries(node, n):
+    # diagonal groups of 512 rows, blocks of 64, follower range 448: sizes that leave partial groups,
+    # one-row blocks and empty follower ranges
+    A0, B0 = O.random_fullpos_pair(n)
+    H, T, Q, Z = run_host(node, A0, B0)
+    check_structure(H, T)
+    ra, rb, oq, oz = residuals(A0, B0, H, T, Q, Z)
+    assert max(ra, rb, oq, oz) < WARN_U
+
+
 @pytest.mark.parametrize("n", [1000, 2500])
 def test_device_api_residuals(node, n):
     import torch

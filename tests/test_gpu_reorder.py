@@ -154,3 +154,20 @@ def test_device_resident_reorder_n5000(node):
     assert np.array_equal(sel, (np.arange(n) < k).astype(np.int32))
     assert np.all(r2[:k] > thr - 1e-8) and np.all(r2[k:] <= thr + 1e-8)
     assert np.abs(np.array(sorted(r2[:k])) - np.array(eigs)).max() <= 1e-7 * np.abs(real).max()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_selections_many_windows_per_round(node, seed):
+    # scattered selections: every round holds many disjoint windows (reordered by several host
+    # threads), 2x2 blocks land on window boundaries
+    n = 1500
+    A0, S, Q, real, imag = schur_of_lcg(node, n)
+    rng = np.random.default_rng(seed)
+    sel = (rng.random(n) < 0.4).astype(np.int32)
+    for i in range(n - 1):
+        if imag[i] > 0.0:
+            sel[i] = sel[i + 1] = max(sel[i], sel[i + 1])
+    eigs = [real[i] + 1j * imag[i] for i in range(n) if sel[i]]
+    r2 = np.zeros(n); i2 = np.zeros(n)
+    assert node.SEP_SM_ReorderSchur(n, sel, S, S.shape[0], Q, Q.shape[0], r2, i2) == 0
+    check_reordered(A0, S, Q, r2, i2, eigs, sel, n)
