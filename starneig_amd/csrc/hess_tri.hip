@@ -140,6 +140,10 @@ __global__ __launch_bounds__(64) void ht_qr_tfactor_kernel(int nb, double const 
 constexpr int HG = 8;               // waves of the chain workgroup that hold the rows of the group
 constexpr int HF = 7;               // follower waves: the 64*HF rows above the group
 constexpr int HGR = 64 * HG;        // rows of one diagonal group
+constexpr int HGR_MAX = 512;
+static_assert(HGR <= HGR_MAX, "the LDS column pass holds one group");
+
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 __device__ inline double readlane_d(double v, int l)
 {
@@ -391,6 +395,61 @@ __global__ __launch_bounds__(64) void ht_colpass_kernel(ColJob j0, ColJob j1, Co
     job.M[(size_t)(t_lo - 1) * job.ld + row] = y;
 }
 
+// The same column rotations for the rows of B that the NEXT chain launch waits for: the plain kernel
+// above spends one memory latency per batch of columns on every row (50 us for 512 rotations however
+// few rows there are).  Here a workgroup stages 32 rows x all columns of the group in LDS with every
+// load in flight at once, one half-wave runs the 512-step recurrence out of LDS, and the block goes
+// back in one sweep of stores.
+constexpr int CL_ROWS = 32, CL_COLS = HGR_MAX + 1;
+constexpr int CL_LDS_BYTES = (CL_COLS * CL_ROWS + 2 * HGR_MAX) * 8;
+__global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict__ M, int ld, int rows,
+    int t_hi, int t_lo, double const *__restrict__ Cc, double const *__restrict__ Cs)
+{
+    extern __shared__ double lds[];
+    double (*tile)[CL_ROWS] = (double (*)[CL_ROWS])lds;             // [column t - (t_lo - 1)][row]
+    v2d *cs = (v2d *)(lds + CL_COLS * CL_ROWS);                     // [t - t_lo]
+    int const tid = threadIdx.x, r = tid & (CL_ROWS - 1), sub = tid / CL_ROWS;      // 8 column phases
+    int const row = blockIdx.x * CL_ROWS + r;
+    int const ncol = t_hi - t_lo + 2;                               // columns t_lo - 1 .. t_hi
+    bool const rv = row < rows;
+    double const *src = M + (size_t)(t_lo - 1) * ld + row;
+    for (int c0 = sub; c0 < ncol; c0 += 8 * 33) {                   // (513 columns / 8 phases: two batches)
+        double v[33];
+#pragma unroll
+        for (int i = 0; i < 33; i++) v[i] = (rv && c0 + 8 * i < ncol) ? src[(size_t)(c0 + 8 * i) * ld] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 33; i++) if (c0 + 8 * i < ncol) tile[c0 + 8 * i][r] = v[i];
+    }
+    for (int i = tid; i < ncol - 1; i += 256) cs[i] = v2d{Cc[t_lo + i], Cs[t_lo + i]};
+    __syncthreads();
+    if (tid < CL_ROWS) {
+        double y = tile[ncol - 1][r];
+        int i = ncol - 2;                                           // rotation t = t_lo + i: columns i (t-1) and i+1 (t)
+        for (; i >= 7; i -= 8) {                                    // reads of a batch first: the writes go to other columns
+            double x[8]; v2d k[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { x[q] = tile[i - q][r]; k[q] = cs[i - q]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                tile[i - q + 1][r] = k[q].y * x[q] + k[q].x * y;
+                y = k[q].x * x[q] - k[q].y * y;
+            }
+        }
+        for (; i >= 0; i--) {
+            double const x = tile[i][r];
+            v2d const k = cs[i];
+            tile[i + 1][r] = k.y * x + k.x * y;
+            y = k.x * x - k.y * y;
+        }
+        tile[0][r] = y;
+    }
+    __syncthreads();
+    if (rv) {
+        double *dst = M + (size_t)(t_lo - 1) * ld + row;
+        for (int c = sub; c < ncol; c += 8) dst[(size_t)c * ld] = tile[c][r];
+    }
+}
+
 // The chain of one diagonal group, rows [g0, g1): B is upper Hessenberg there (fill-in of the row
 // pass); rotation t = g1-1 .. max(g0, j+2) of columns (t-1, t) is dlartg(B(t,t), B(t,t-1)) on the
 // CURRENT entries.  One lane per row; a lane carries the current value of column t of its row.
@@ -405,7 +464,6 @@ constexpr int CHAIN_LDS_DOUBLES(int) { return NTB * 65 * 64; }
 // instructions: a C++ volatile or atomic access through a generic pointer becomes a FLAT
 // instruction with system scope followed by s_waitcnt vmcnt(0) -- a wait for every load and store
 // of the wave, on the chain.
-typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ inline unsigned lds_addr(void const *p) { return (unsigned)(size_t)p; }
 __device__ inline void lds_store(unsigned addr, int v)
 {
@@ -749,6 +807,7 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     hipStream_t const side = ws.side;
     static bool attr_set = false;
     if (!attr_set) {
+        SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht_colpass_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS_BYTES));
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht_chain_kernel<HG, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_DOUBLES(HG) * 8));
         attr_set = true;
     }
@@ -780,8 +839,8 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
             // the rows of B above the followers: next on the chain's own stream (the next launch needs
             // them); A and Z: on the side stream, nobody waits for them before the sweep ends
             if (near_lo > 0)
-                hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(near_lo, 64), 1), dim3(64), 0, s,
-                    ColJob{dB, ldB, near_lo}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
+                hipLaunchKernelGGL(ht_colpass_lds_kernel, dim3(divceil(near_lo, CL_ROWS)), dim3(256), CL_LDS_BYTES, s,
+                    dB, ldB, near_lo, t_hi, t_lo, ws.Cc, ws.Cs);
             SN_HIP_CHECK(hipStreamWaitEvent(side, ws.e_chain[gi], 0));
             hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 2), dim3(64), 0, side,
                 ColJob{dA, ldA, n}, ColJob{dZ, ldZ, dZ ? n : 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
