@@ -11,7 +11,7 @@ L.sn_internal_ht_chain_bench.argtypes = [C.c_int, C.c_int]
 names = {0: "4 group waves + 12 followers", 1: "4 group waves, no followers", 2: "4 + 4 followers", 3: "no loads", 4: "no result stores",
          5: "no safe-range branch", 6: "no loads, no stores, no branch", 7: "6 + no barrier, no apply", 8: "one wave, 64 rotations",
          9: "one wave, 64 rotations, bare"}
-names[10] = 'timestamps, full kernel'; names[12] = '8 group waves + 7 followers, 512 rotations'; names[0] = '4 group waves + 11 followers'
+names[10] = 'timestamps, full kernel'; names[12] = '8 group waves, no followers, 512 rotations'; names[0] = '4 group waves + 11 followers'
 for v in (sys.argv[1:] and [int(a) for a in sys.argv[1:]]) or range(10):
     us = L.sn_internal_ht_chain_bench(v, 20)
     steps = {8: 64, 12: 512}.get(v, 256)

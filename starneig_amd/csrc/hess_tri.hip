@@ -17,9 +17,9 @@
 //               of squares of the column (a parallel scan instead of n dependent dlartg calls);
 //      row pass the row rotations on A and B (one lane per column, LDS-transposed tiles);
 //      chain    the fill-in of B (now upper Hessenberg) is removed by the column rotations, a
-//               dependent chain along the diagonal: one workgroup per group of 512 rows, one lane
-//               per row, the current column pair in registers, the rotation built from two lane
-//               reads; the other waves of the workgroup follow block by block;
+//               dependent chain along the diagonal: one workgroup per group of 256 rows, one lane
+//               per row, the diagonal tile in LDS, the rotation built from two lane reads; the
+//               other waves of the workgroup follow block by block;
 //      col pass the column rotations of a finished group on the rows above (B), on A and on Z,
 //               one lane per row, coalesced column loads; Q takes the row rotations the same way.
 //    The chain is what bounds the step (n^2/2 dependent rotations); everything else streams.
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(64) void ht_qr_tfactor_kernel(int nb, double const 
 // ---------------------------------------------------------------------------------------------
 // Rotation step
 // ---------------------------------------------------------------------------------------------
-constexpr int HG = 8;               // waves of the chain workgroup that hold the rows of the group
-constexpr int HF = 7;               // follower waves: the 64*HF rows above the group
+constexpr int HG = 4;              // waves of the chain workgroup that hold the rows of the group
+constexpr int HF = 0;               // follower waves: the 64*HF rows above the group
 constexpr int HGR = 64 * HG;        // rows of one diagonal group
 constexpr int HGR_MAX = 512;
 static_assert(HGR <= HGR_MAX, "the LDS column pass holds one group");
@@ -408,17 +408,18 @@ __global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict_
     extern __shared__ double lds[];
     double (*tile)[CL_ROWS] = (double (*)[CL_ROWS])lds;             // [column t - (t_lo - 1)][row]
     v2d *cs = (v2d *)(lds + CL_COLS * CL_ROWS);                     // [t - t_lo]
-    int const tid = threadIdx.x, r = tid & (CL_ROWS - 1), sub = tid / CL_ROWS;      // 8 column phases
+    int const tid = threadIdx.x, r = tid & (CL_ROWS - 1), sub = tid / CL_ROWS;      // NPH column phases
+    constexpr int NPH = 256 / CL_ROWS, NLD = (CL_COLS + 2 * NPH - 1) / (2 * NPH);   // two batches of NLD loads
     int const row = blockIdx.x * CL_ROWS + r;
     int const ncol = t_hi - t_lo + 2;                               // columns t_lo - 1 .. t_hi
     bool const rv = row < rows;
     double const *src = M + (size_t)(t_lo - 1) * ld + row;
-    for (int c0 = sub; c0 < ncol; c0 += 8 * 33) {                   // (513 columns / 8 phases: two batches)
-        double v[33];
+    for (int c0 = sub; c0 < ncol; c0 += NPH * NLD) {
+        double v[NLD];
 #pragma unroll
-        for (int i = 0; i < 33; i++) v[i] = (rv && c0 + 8 * i < ncol) ? src[(size_t)(c0 + 8 * i) * ld] : 0.0;
+        for (int i = 0; i < NLD; i++) v[i] = (rv && c0 + NPH * i < ncol) ? src[(size_t)(c0 + NPH * i) * ld] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 33; i++) if (c0 + 8 * i < ncol) tile[c0 + 8 * i][r] = v[i];
+        for (int i = 0; i < NLD; i++) if (c0 + NPH * i < ncol) tile[c0 + NPH * i][r] = v[i];
     }
     for (int i = tid; i < ncol - 1; i += 256) cs[i] = v2d{Cc[t_lo + i], Cs[t_lo + i]};
     __syncthreads();
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict_
     __syncthreads();
     if (rv) {
         double *dst = M + (size_t)(t_lo - 1) * ld + row;
-        for (int c = sub; c < ncol; c += 8) dst[(size_t)c * ld] = tile[c][r];
+        for (int c = sub; c < ncol; c += NPH) dst[(size_t)c * ld] = tile[c][r];
     }
 }
 
@@ -897,7 +898,7 @@ double sn_internal_ht_chain_bench(int variant, int reps)
             case 5: go(ht_chain_kernel<4, 0, 4>, 4, 0, g0); break;
             case 8: go(ht_chain_kernel<1, 0>, 1, 0, n - 64); break;
             case 10: go(ht_chain_kernel<4, 0, 32>, 4, 0, g0); break;
-            case 12: go(ht_chain_kernel<8, 7>, 8, 7, n - 512); break;
+            case 12: go(ht_chain_kernel<8, 0>, 8, 0, n - 512); break;
             default: go(ht_chain_kernel<4, 11>, 4, 11, g0);
         }
         SN_HIP_CHECK(hipEventRecord(e1, nullptr));
