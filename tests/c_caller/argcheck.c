@@ -81,6 +81,21 @@ int main(void)
     EXPECT(starneig_GEP_SM_Schur_expert(&sc, n, A, ld, B, ld, Q, ld, Z, n - 1, re, im, be), -10);
     EXPECT(starneig_GEP_SM_Schur_expert(&sc, n, A, ld, B, ld, Q, ld, Z, ld, NULL, NULL, NULL), STARNEIG_NOT_INITIALIZED);
 
+    /* wrappers/lapack.c:65-73, common/combined.c:110-118 */
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(0, A, ld, B, ld, Q, ld, Z, ld), -1);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, NULL, ld, B, ld, Q, ld, Z, ld), -2);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, n - 1, B, ld, Q, ld, Z, ld), -3);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, NULL, ld, Q, ld, Z, ld), -4);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, n - 1, Q, ld, Z, ld), -5);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, ld, NULL, ld, Z, ld), -6);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, ld, Q, n - 1, Z, ld), -7);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, ld, Q, ld, NULL, ld), -8);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, ld, Q, ld, Z, n - 1), -9);
+    EXPECT(starneig_GEP_SM_HessenbergTriangular(n, A, ld, B, ld, Q, ld, Z, ld), STARNEIG_NOT_INITIALIZED);
+    EXPECT(starneig_GEP_SM_Reduce(0, A, ld, B, ld, Q, ld, Z, ld, re, im, be, NULL, NULL, NULL, NULL), -1);
+    EXPECT(starneig_GEP_SM_Reduce(n, A, ld, B, ld, Q, ld, Z, n - 1, re, im, be, NULL, NULL, NULL, NULL), -9);
+    EXPECT(starneig_GEP_SM_Reduce(n, A, ld, B, ld, Q, ld, Z, ld, re, im, be, NULL, NULL, NULL, NULL), STARNEIG_NOT_INITIALIZED);
+
     EXPECT(starneig_SEP_SM_Reduce(0, A, ld, Q, ld, re, im, NULL, NULL, NULL, NULL), -1);
     EXPECT(starneig_SEP_SM_Reduce(n, NULL, ld, Q, ld, re, im, NULL, NULL, NULL, NULL), -2);
     EXPECT(starneig_SEP_SM_Reduce(n, A, n - 1, Q, ld, re, im, NULL, NULL, NULL, NULL), -3);
