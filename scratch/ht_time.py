@@ -14,8 +14,11 @@ tA0, tB0 = tA.clone(), tB.clone()
 tQ = S.device_matrix(n); S.set_matrix_device(tQ, n, n, 0.0, 1.0)
 tZ = S.device_matrix(n); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
 torch.cuda.synchronize(); t = time.time()
-rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+noqz = os.environ.get('HT_NOQZ') == '1'
+rc, st = S.hessenberg_triangular_device(tA, tB, None if noqz else tQ, None if noqz else tZ, n=n)
 torch.cuda.synchronize(); t = time.time() - t
+if noqz:
+    print(f'n={n} without Q, Z: rotations {st["rotation_ms"]/1e3:.3f}s'); sys.exit(0)
 _, ca = S.check_pencil_device(tQ, tA, tZ, tA0, n=n)
 _, cb = S.check_pencil_device(tQ, tB, tZ, tB0, n=n)
 print(f"n={n} rc={rc} wall {t:.2f}s qr {st['qr_ms']/1e3:.3f}s rotations {st['rotation_ms']/1e3:.3f}s "

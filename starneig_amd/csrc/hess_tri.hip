@@ -24,6 +24,7 @@
 //               one lane per row, coalesced column loads; Q takes the row rotations the same way.
 //    The chain is what bounds the step (n^2/2 dependent rotations); everything else streams.
 #include "common.h"
+#include <starneig/error.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -502,7 +503,8 @@ __device__ inline void ht_wait(unsigned ctr, int which, int need)
 //    writes the finished ones, and the rotations, back.
 template <int G, int F, int DBG = 0>
 __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j, int g0, int g1,
-    double *__restrict__ B, int ldb, double *__restrict__ Cc, double *__restrict__ Cs, long long *ts = nullptr)
+    double *__restrict__ B, int ldb, double *__restrict__ Cc, double *__restrict__ Cs, long long *ts = nullptr,
+    int *err = nullptr)
 {
     extern __shared__ double lds[];
     double (*tile)[65][64] = (double (*)[65][64])lds;                   // [buffer][column slot][row]
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
             ht_wait(ctr, 2, k + 1);
             flush(k);
         }
+        if (err && lane == 0 && lds_load(ctr + 12) != 0) *err = 1;     // a wait gave up: the host reports it
         return;
     }
 
@@ -725,7 +728,7 @@ struct HtWorkspace {
         for (int b = 0; b < 2; b++) { alloc(part[b], (size_t)divceil(n, QROWS) * QP); alloc(prow[b], QNB); }
         for (int b = 0; b < 2; b++) { alloc(Rc2[b], n); alloc(Rs2[b], n); }
         alloc(Cc, n); alloc(Cs, n);
-        if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 8));
+        if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 16));       // [0] max |b|, [1] error flag of the chain kernels
         for (int b = 0; b < 2; b++) {
             alloc(rp_beta[b], (size_t)divceil(n, 64) * n); alloc(rp_up[b], (size_t)divceil(n, 64) * n); alloc(rp_alpha[b], divceil(n, 64));
         }
@@ -795,7 +798,7 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     ws.ensure(n);
     double flops = 0.0, rotations = 0.0;
     SN_HIP_CHECK(hipEventRecord(ws.ev[0], s));
-    SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 8, s));
+    SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 16, s));
     hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dB, ldB, ws.amax);
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, 1);
     ht_qr_step(s, ws, n, dA, ldA, dB, ldB, dQ, ldQ, &flops);
@@ -833,7 +836,8 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
             int const g0 = std::max(0, (g1 - 1) / HGR * HGR);
             // the rows that enter the followers of this launch were updated last by the side stream's
             // column pass of the previous group
-            hipLaunchKernelGGL((ht_chain_kernel<HG, HF>), dim3(1), dim3(64 * (HG + HF + 1)), CHAIN_LDS_DOUBLES(HG) * 8, s, n, j, g0, g1, dB, ldB, ws.Cc, ws.Cs, (long long *)nullptr);
+            hipLaunchKernelGGL((ht_chain_kernel<HG, HF>), dim3(1), dim3(64 * (HG + HF + 1)), CHAIN_LDS_DOUBLES(HG) * 8, s, n, j, g0, g1, dB, ldB, ws.Cc, ws.Cs, (long long *)nullptr,
+                (int *)(ws.amax + 1));
             SN_HIP_CHECK(hipEventRecord(ws.e_chain[gi], s));
             int const t_hi = g1 - 1, t_lo = std::max(g0, j + 2);
             int const near_lo = std::max(0, g0 - 64 * HF);          // rows [near_lo, g0): followers of the chain kernel
@@ -853,6 +857,8 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));
     if (dQ && n > 2) { SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0)); if (n > 3) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0)); }
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, -1);
+    int chain_err = 0;
+    SN_HIP_CHECK(hipMemcpyAsync(&chain_err, ws.amax + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SN_HIP_CHECK(hipEventRecord(ws.ev[2], s));
     SN_HIP_CHECK(hipStreamSynchronize(s));
     if (stats) {
@@ -860,6 +866,11 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
         SN_HIP_CHECK(hipEventElapsedTime(&t01, ws.ev[0], ws.ev[1]));
         SN_HIP_CHECK(hipEventElapsedTime(&t12, ws.ev[1], ws.ev[2]));
         stats[0] = t01 + t12; stats[1] = t01; stats[2] = t12; stats[3] = flops; stats[4] = rotations;
+    }
+    if (chain_err) {
+        fprintf(stderr, "[starneig-amd] Hessenberg-triangular reduction: a wait inside the chain kernel timed out; "
+            "the result is not valid.\n");
+        return STARNEIG_GENERIC_ERROR;
     }
     return 0;
 }
@@ -890,7 +901,7 @@ double sn_internal_ht_chain_bench(int variant, int reps)
         SN_HIP_CHECK(hipEventRecord(e0, nullptr));
         auto go = [&](auto kern, int G_, int F_, int gg0) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_DOUBLES(G_) * 8));
-            hipLaunchKernelGGL(kern, dim3(1), dim3(64 * (G_ + F_ + 1)), CHAIN_LDS_DOUBLES(G_) * 8, nullptr, n, 0, gg0, g1, B, ld, Cc, Cs, ts);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(64 * (G_ + F_ + 1)), CHAIN_LDS_DOUBLES(G_) * 8, nullptr, n, 0, gg0, g1, B, ld, Cc, Cs, ts, (int *)nullptr);
         };
         switch (variant) {
             case 1: go(ht_chain_kernel<4, 0>, 4, 0, g0); break;
