@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void ht_qr_tfactor_kernel(int nb, double const 
 constexpr int HG = 4;              // waves of the chain workgroup that hold the rows of the group
 constexpr int HF = 0;               // follower waves: the 64*HF rows above the group
 constexpr int HGR = 64 * HG;        // rows of one diagonal group
-constexpr int HGR_MAX = 512;
+constexpr int HGR_MAX = 256;
 static_assert(HGR <= HGR_MAX, "the LDS column pass holds one group");
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -699,7 +699,7 @@ struct HtWorkspace {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipStream_t side = nullptr, qstream = nullptr;
     hipEvent_t e_scan = nullptr, e_side = nullptr, e_q[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> e_chain, e_rest;
+    std::vector<hipEvent_t> e_chain;                    // one per diagonal group of a sweep
     void ensure(int n_)
     {
         if (!ev[0]) {
@@ -713,10 +713,9 @@ struct HtWorkspace {
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_side, hipEventDisableTiming));
         }
         while ((int)e_chain.size() < divceil(n_, HGR) + 1) {
-            hipEvent_t a, b;
+            hipEvent_t a;
             SN_HIP_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-            SN_HIP_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-            e_chain.push_back(a); e_rest.push_back(b);
+            e_chain.push_back(a);
         }
         if (n_ <= n) return;
         release_buffers();
