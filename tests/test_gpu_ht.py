@@ -105,6 +105,28 @@ def test_device_api_residuals(node, n):
     assert ca["orthogonality_q_u"] < WARN_U and ca["orthogonality_z_u"] < WARN_U
 
 
+def test_device_api_without_q_and_z(node):
+    # dQ = dZ = NULL: (H, T) alone; the same pencil as with the factors (up to the run-to-run
+    # rounding of the split-K sums in the QR step)
+    import torch
+    n = 700
+    A0, B0 = O.random_fullpos_pair(n)
+    out = []
+    for with_qz in (True, False):
+        tA, tB = to_device(A0), to_device(B0)
+        tQ = tZ = None
+        if with_qz:
+            tQ = node.device_matrix(n, ld=tA.shape[1]); node.set_matrix_device(tQ, n, n, 0.0, 1.0)
+            tZ = node.device_matrix(n, ld=tA.shape[1]); node.set_matrix_device(tZ, n, n, 0.0, 1.0)
+        rc, _ = node.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+        assert rc == 0
+        out.append((to_host(tA), to_host(tB)))
+    (H1, T1), (H2, T2) = out
+    check_structure(H2, T2)
+    assert np.abs(H1 - H2).max() <= 1e-8 * np.abs(H1).max()
+    assert np.abs(T1 - T2).max() <= 1e-8 * np.abs(T1).max()
+
+
 def test_accumulates_into_given_q_and_z(node):
     n = 150
     A0, B0 = O.random_fullpos_pair(n)
