@@ -515,7 +515,22 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
     int const t_hi = g1 - 1, t_lo = std::max(g0, j + 2);
     int const wtop = std::min(G - 1, (t_hi - g0) / 64), wbot = (t_lo - g0) / 64;
     int const K = wtop - wbot + 1;                                      // blocks with rotations, k = wtop - wb
-    if (threadIdx.x == 0) { ctr_words[0] = 0; ctr_words[1] = 0; ctr_words[2] = 0; ctr_words[3] = 0; }
+    if (threadIdx.x == 0) { ctr_words[0] = 0; ctr_words[1] = 1; ctr_words[2] = 0; ctr_words[3] = 0; }
+    {
+        // the first diagonal tile: all waves of the workgroup fetch it together (the chain cannot start
+        // before it is in LDS; the loader alone needs four rounds of loads for it)
+        int const b0 = g0 + 64 * wtop, q_hi = std::min(63, t_hi - b0), q_lo = std::max(0, t_lo - b0);
+        int const nw = G + F + 1, per = (q_hi - q_lo + nw) / nw;          // columns per wave
+        double const *src = B + (size_t)(b0 - 1) * ldb + b0 + lane;
+        for (int off = 0; off < per; off += 16) {
+            int const c0 = q_lo + per * wv + off;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = (off + i < per && c0 + i <= q_hi && lane <= q_hi) ? src[(size_t)(c0 + i) * ldb] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (off + i < per && c0 + i <= q_hi) tile[0][c0 + i][lane] = v[i];
+        }
+    }
     __syncthreads();
     if ((DBG & 32) && ts && threadIdx.x == 0) ts[63] = wall_clock64();
 
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(64 * (G + F + 1)) void ht_chain_kernel(int n, int j
             int const t = b0 + lane;
             if (lane >= q_lo && lane <= q_hi) { Cc[t] = rot[t_hi - t][0]; Cs[t] = rot[t_hi - t][1]; }
         };
-        for (int k = 0; k < K; k++) {
+        for (int k = 1; k < K; k++) {                   // (tile 0 came in at the start)
             if (k >= NTB) {
                 ht_wait(ctr, 2, k - NTB + 1);
                 flush(k - NTB);
