@@ -186,3 +186,39 @@ def test_helper_threads_reproduce_the_serial_kernels_bit_for_bit(n):
     L.sn_internal_helper_session(0)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+
+
+def test_reorder_window_rejected_swap_keeps_a_valid_decomposition():
+    """A selected 2x2 block below an unselected 2x2 block with (almost) the same eigenvalue pair:
+    the Sylvester equation of the exchange is (nearly) singular, dlaexc's acceptance test rejects
+    the swap (reorder/cpu.c -> STARNEIG_PARTIAL_REORDERING).  The kernel must then report `failed`,
+    leave a valid similarity behind and keep the marks on the rows where the blocks now are."""
+    L = S.lib.load()
+    ip = C.POINTER(C.c_int)
+    L.sn_internal_reorder_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, ip, ip]
+    n = 8
+    rng = np.random.default_rng(3)
+    T = np.asfortranarray(np.triu(rng.standard_normal((n, n))))
+    blk = np.array([[1.0, 2.0], [-0.5, 1.0]])                   # standardised 2x2 block, eigenvalues 1 +- i
+    T[0:2, 0:2] = [[3.0, 0.1], [0.0, 4.0]]                      # two real eigenvalues, unselected
+    T[2:4, 2:4] = blk                                           # unselected pair
+    T[4:6, 4:6] = blk * (1.0 + 1e-15)                           # selected pair: the same eigenvalues up to rounding
+    T[6:8, 6:8] = [[-2.0, 0.3], [0.0, -3.0]]
+    for i in (0, 1, 3, 5, 6):                                   # clean the sub-diagonal outside the two pairs
+        if i + 1 < n and i not in (2, 4):
+            T[i + 1, i] = 0.0
+    T[3, 2] = blk[1, 0]; T[5, 4] = blk[1, 0] * (1.0 + 1e-15)
+    T0 = T.copy(order="F")
+    sel = np.zeros(n, dtype=np.int32); sel[4] = sel[5] = 1
+    Z = np.asfortranarray(np.eye(n)); failed = C.c_int(0)
+    placed = L.sn_internal_reorder_window(n, P(T), n, P(Z), n, sel.ctypes.data_as(ip), C.byref(failed))
+    assert is_quasi_triangular(T)
+    assert np.linalg.norm(Z @ T @ Z.T - T0) <= 500 * U * np.linalg.norm(T0)
+    assert np.linalg.norm(Z @ Z.T - np.eye(n)) <= 200 * U * np.sqrt(n)
+    if failed.value:
+        # nothing reached the top; the selected pair still carries its marks, wherever it stopped
+        assert placed == 0 and sel.sum() == 2
+        i = int(np.argmax(sel))
+        assert sel[i + 1] == 1 and T[i + 1, i] != 0.0
+    else:
+        assert placed == 2 and np.array_equal(sel, (np.arange(n) < 2).astype(np.int32))
