@@ -38,8 +38,20 @@ starneig_error_t starneig_amd_hessenberg_device(
  * >= n*panel_width doubles), ld = starneig_amd_hessenberg_panel_ld(n, panel_width), and
  * supplies allreduce_sum / broadcast callbacks that act on (buffer, offset, count) with
  * buffer 0 = dY, 1 = dP, 2 = dW, 3 = dA, 4 = dQ, ordered on `stream`
- * (torch.distributed over RCCL in starneig_amd/distributed.py). */
+ * (torch.distributed over RCCL in starneig_amd/distributed.py).  With BOTH callbacks NULL the
+ * collectives are issued to RCCL directly on `stream` (no host round trip per panel column), through
+ * the communicator of starneig_amd_rccl_init. */
 int starneig_amd_hessenberg_panel_ld(int n, int panel_width);
+
+/* RCCL called directly (librccl.so is opened at run time).  One communicator per process: rank 0
+ * obtains the 128-byte id, the caller carries it to the other ranks (any transport), every rank
+ * calls _init(rank, world, id).  _allreduce_sum / _broadcast act in place on device doubles, ordered
+ * on `stream`.  All return 0 on success. */
+int starneig_amd_rccl_unique_id(void *id128);
+int starneig_amd_rccl_init(int rank, int world, void const *id128);
+void starneig_amd_rccl_finalize(void);
+int starneig_amd_rccl_allreduce_sum(double *dbuf, long count, void *stream);
+int starneig_amd_rccl_broadcast(double *dbuf, long count, int root, void *stream);
 starneig_error_t starneig_amd_hessenberg_sharded_device(
     int n, int panel_width, double *dA, int ldA, double *dQ, int ldQ,
     double *dY, double *dP, double *dW, long w_capacity,

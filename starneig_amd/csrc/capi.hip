@@ -746,6 +746,26 @@ SN_API int starneig_amd_hessenberg_panel_ld(int n, int panel_width)
     return sn::hessenberg_panel_ld(n, panel_width);
 }
 
+namespace {
+struct NativeComm { double *buf[5]; hipStream_t s; };        // buffer ids of sn::HessComm: y, panel, W, A, Q
+void native_allreduce(void *ctx, int buffer, long offset, long count)
+{
+    NativeComm *c = (NativeComm *)ctx;
+    if (sn::rccl_allreduce_sum(c->buf[buffer] + offset, count, c->s) != 0) abort();   // a rank that drops out would hang the others
+}
+void native_broadcast(void *ctx, int buffer, long offset, long count, int root)
+{
+    NativeComm *c = (NativeComm *)ctx;
+    if (sn::rccl_broadcast(c->buf[buffer] + offset, count, root, c->s) != 0) abort();
+}
+}
+
+SN_API int starneig_amd_rccl_unique_id(void *id128) { return sn::rccl_unique_id(id128); }
+SN_API int starneig_amd_rccl_init(int rank, int world, void const *id128) { return sn::rccl_init(rank, world, id128); }
+SN_API void starneig_amd_rccl_finalize(void) { sn::rccl_finalize(); }
+SN_API int starneig_amd_rccl_allreduce_sum(double *dbuf, long count, void *stream) { return sn::rccl_allreduce_sum(dbuf, count, (hipStream_t)stream); }
+SN_API int starneig_amd_rccl_broadcast(double *dbuf, long count, int root, void *stream) { return sn::rccl_broadcast(dbuf, count, root, (hipStream_t)stream); }
+
 SN_API starneig_error_t starneig_amd_hessenberg_sharded_device(
     int n, int panel_width, double *dA, int ldA, double *dQ, int ldQ,
     double *dY, double *dP, double *dW, long w_capacity,
@@ -759,14 +779,19 @@ SN_API starneig_error_t starneig_amd_hessenberg_sharded_device(
     if (ldA < n)               return -4;
     if (dQ != NULL && ldQ < n) return -6;
     if (dY == NULL || dP == NULL || dW == NULL) return STARNEIG_INVALID_ARGUMENTS;
-    if (world < 1 || rank < 0 || rank >= world || !allreduce_sum || !broadcast)
-        return STARNEIG_INVALID_ARGUMENTS;
+    if (world < 1 || rank < 0 || rank >= world) return STARNEIG_INVALID_ARGUMENTS;
+    // both callbacks NULL: the collectives go to RCCL directly, on `stream` (starneig_amd_rccl_init first)
+    bool const native = !allreduce_sum && !broadcast;
+    if (!native && (!allreduce_sum || !broadcast)) return STARNEIG_INVALID_ARGUMENTS;
+    if (native && !sn::rccl_ready(rank, world)) return STARNEIG_INVALID_ARGUMENTS;
     if (!g_node.initialized) return STARNEIG_NOT_INITIALIZED;
     if (panel_width <= 0) panel_width = default_panel_width(n);
     if (panel_width < 8) return STARNEIG_INVALID_CONFIGURATION;
-    sn::HessComm comm{rank, world, allreduce_sum, broadcast, ctx};
-    sn::HessenbergTimings tm;
     hipStream_t s = (hipStream_t)stream;
+    NativeComm nc{{dY, dP, dW, dA, dQ}, s};
+    sn::HessComm comm{rank, world, native ? native_allreduce : allreduce_sum, native ? native_broadcast : broadcast,
+                      native ? (void *)&nc : ctx};
+    sn::HessenbergTimings tm;
     int rc = sn::hessenberg_sharded_device(s, n, panel_width, dA, ldA, dQ, ldQ, dY, dP, dW,
         w_capacity, comm, stats ? &tm : nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(s));

@@ -84,6 +84,13 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     double *dYsum, double *dP, double *dW2, long w2_capacity,
     HessComm const &comm, HessenbergTimings *timings);
 int hessenberg_panel_ld(int n, int panel_width);
+// RCCL called directly (rccl_native.hip; librccl.so opened at run time)
+int rccl_unique_id(void *id128);
+int rccl_init(int rank, int world, void const *id128);
+void rccl_finalize();
+bool rccl_ready(int rank, int world);
+int rccl_allreduce_sum(double *buf, long count, hipStream_t s);
+int rccl_broadcast(double *buf, long count, int root, hipStream_t s);
 
 // ---- Schur (schur.hip) -----------------------------------------------------------
 struct SchurParams {            // resolved from starneig_schur_conf (negative = default)

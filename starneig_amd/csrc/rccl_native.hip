@@ -1,0 +1,94 @@
+// RCCL called directly ("RCCL broadcast of the WY block", per-column all-reduce of the
+// sharded gemv): the collectives of the sharded Hessenberg reduction enqueued on the reduction's own
+// stream from C++, instead of one Python callback into torch.distributed per panel column.
+// librccl.so is opened at run time (no link-time dependency: the library still loads on a machine
+// without RCCL and the callback path keeps working).  One communicator per process; the unique id
+// travels through whatever the caller has (starneig_amd/distributed.py: a torch.distributed broadcast).
+#include "common.h"
+#include <dlfcn.h>
+#include <cstring>
+#include <rccl/rccl.h>
+
+namespace sn {
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = -1, world = 0;
+    bool load()
+    {
+        if (handle) return true;
+        handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!handle) handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!handle) return false;
+        auto sym = [&](const char *name) { return dlsym(handle, name); };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !Broadcast) { handle = nullptr; return false; }
+        return true;
+    }
+};
+RcclApi g_rccl;
+
+bool check(ncclResult_t r, const char *what)
+{
+    if (r == ncclSuccess) return true;
+    fprintf(stderr, "[starneig-amd] RCCL %s failed: %s\n", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return false;
+}
+
+} // namespace
+
+int rccl_unique_id(void *id128)
+{
+    if (!g_rccl.load()) return 1;
+    ncclUniqueId id;
+    if (!check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId")) return 2;
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int rccl_init(int rank, int world, void const *id128)
+{
+    if (!g_rccl.load()) return 1;
+    if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    if (!check(g_rccl.CommInitRank(&g_rccl.comm, world, id, rank), "ncclCommInitRank")) { g_rccl.comm = nullptr; return 2; }
+    g_rccl.rank = rank; g_rccl.world = world;
+    return 0;
+}
+
+void rccl_finalize()
+{
+    if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
+    g_rccl.rank = -1; g_rccl.world = 0;
+}
+
+bool rccl_ready(int rank, int world) { return g_rccl.comm && g_rccl.rank == rank && g_rccl.world == world; }
+
+int rccl_allreduce_sum(double *buf, long count, hipStream_t s)
+{
+    if (!g_rccl.comm) return 1;
+    return check(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_rccl.comm, s), "ncclAllReduce") ? 0 : 2;
+}
+
+int rccl_broadcast(double *buf, long count, int root, hipStream_t s)
+{
+    if (!g_rccl.comm) return 1;
+    return check(g_rccl.Broadcast(buf, buf, (size_t)count, ncclDouble, root, g_rccl.comm, s), "ncclBroadcast") ? 0 : 2;
+}
+
+} // namespace sn

@@ -1,9 +1,13 @@
-"""Multi-GPU driver of the sharded Hessenberg reduction: one process per GPU,
-torch.distributed (backend "nccl" = RCCL over xGMI) provides the collectives.
+"""Multi-GPU driver of the sharded Hessenberg reduction: one process per GPU over RCCL / xGMI.
 
-The C library does all the compute and calls back into this module for the two collectives
-it needs (all-reduce-sum, broadcast) on buffers that this module allocated; torch is
-plumbing only (device memory, the stream, the process group).
+The C library does all the compute.  Its two collectives (all-reduce-sum, broadcast) go to RCCL
+directly from C++ on the reduction's own stream when the process group runs on "nccl" (= RCCL):
+this module only carries the communicator's unique id to the ranks (one torch.distributed
+broadcast) and checks the new communicator with a small all-reduce and broadcast before using
+it.  Otherwise (gloo, a sub-group, SN_NATIVE_RCCL=0, or a failed check) the library calls back
+into this module and the collectives are torch.distributed calls on buffers allocated here --
+one Python round trip per panel column.  torch is plumbing only (device memory, the stream, the
+process group).
 
 Communication per reduction of an n x n matrix with panel width nb:
   per panel : broadcast of the owner's panel columns  (ld*nb doubles)
@@ -32,6 +36,58 @@ def owned_q_rows(n, world, rank):
     """Contiguous row block of Q owned by `rank` (multiples of 128 rows)."""
     chunk = ((n + world - 1) // world + 127) // 128 * 128
     return min(n, rank * chunk), min(n, (rank + 1) * chunk)
+
+
+_native = {"state": None}       # None: not tried; False: unavailable; (rank, world): communicator ready
+
+
+def native_rccl(group=None):
+    """True when the library's own RCCL communicator is ready for the default process group."""
+    import torch
+    import torch.distributed as dist
+    if group is not None or os.environ.get("SN_NATIVE_RCCL", "1") == "0":
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if _native["state"] is not None:
+        return _native["state"] == (rank, world)
+    _native["state"] = False
+    try:
+        if dist.get_backend() != "nccl":
+            return False
+        L = lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            host = (C.c_ubyte * 128)()
+            if L.starneig_amd_rccl_unique_id(host) != 0:
+                host = None
+            else:
+                ident.copy_(torch.tensor(list(host), dtype=torch.uint8))
+        ok = torch.tensor([1 if (rank != 0 or host is not None) else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(ok, src=0)
+        if int(ok.item()) == 0:
+            return False
+        dist.broadcast(ident, src=0)
+        raw = bytes(ident.cpu().tolist())
+        good = L.starneig_amd_rccl_init(rank, world, raw) == 0
+        if good:
+            # the new communicator against known answers before it carries a reduction
+            stream = torch.cuda.current_stream().cuda_stream
+            t = torch.full((64,), float(rank + 1), dtype=torch.float64, device=dev)
+            good = L.starneig_amd_rccl_allreduce_sum(t.data_ptr(), 64, stream) == 0
+            b = torch.full((64,), float(rank), dtype=torch.float64, device=dev)
+            good = good and L.starneig_amd_rccl_broadcast(b.data_ptr(), 64, world - 1, stream) == 0
+            torch.cuda.synchronize()
+            good = good and bool((t == world * (world + 1) / 2.0).all()) and bool((b == float(world - 1)).all())
+        agree = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 1:
+            _native["state"] = (rank, world)
+            return True
+        L.starneig_amd_rccl_finalize()
+    except Exception as e:          # no RCCL, an old library: the callback path still works
+        sys.stderr.write(f"[starneig-amd] native RCCL not used: {e!r}\n")
+    return False
 
 
 class Collectives:
@@ -90,15 +146,17 @@ def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
     tW = torch.zeros(n * pw, dtype=torch.float64, device=dev)
     coll = Collectives({0: tY, 1: tP, 2: tW, 3: tA.view(-1),
                         4: tQ.view(-1) if tQ is not None else None}, group)
+    native = native_rccl(group)
     st = (C.c_double * 8)()
     rc = L.starneig_amd_hessenberg_sharded_device(
         n, pw, tA.data_ptr(), tA.shape[1], tQ.data_ptr() if tQ is not None else None,
         tQ.shape[1] if tQ is not None else 0, tY.data_ptr(), tP.data_ptr(), tW.data_ptr(),
         tW.numel(), rank, world,
-        C.cast(coll.allreduce_cb, C.c_void_p), C.cast(coll.broadcast_cb, C.c_void_p),
+        None if native else C.cast(coll.allreduce_cb, C.c_void_p),
+        None if native else C.cast(coll.broadcast_cb, C.c_void_p),
         None, torch.cuda.current_stream().cuda_stream, st)
     stats = {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
-             "gemv_launches": int(st[5]), "collectives": dict(coll.calls)}
+             "gemv_launches": int(st[5]), "collectives": "RCCL, called from the library" if native else dict(coll.calls)}
     return rc, stats
 
 

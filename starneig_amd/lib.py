@@ -109,6 +109,11 @@ SIGNATURES = {
     "starneig_amd_hessenberg_sharded_device": (
         C.c_int, [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_long,
                   C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp]),
+    "starneig_amd_rccl_unique_id": (C.c_int, [_vp]),
+    "starneig_amd_rccl_init": (C.c_int, [C.c_int, C.c_int, _vp]),
+    "starneig_amd_rccl_finalize": (None, []),
+    "starneig_amd_rccl_allreduce_sum": (C.c_int, [_vp, C.c_long, _vp]),
+    "starneig_amd_rccl_broadcast": (C.c_int, [_vp, C.c_long, C.c_int, _vp]),
     "starneig_amd_dgemm_device": (
         C.c_int, [C.c_char, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int,
                   _vp, C.c_int, C.c_double, _vp, C.c_int, _vp]),

@@ -16,9 +16,13 @@ import torch.distributed as dist
 
 def main():
     n, pw = int(sys.argv[1]), int(sys.argv[2])
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     torch.cuda.set_device(0)
+    if backend == "nccl":          # (one rank per GPU: RCCL does not share a device between ranks)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     torch.zeros(1, device="cuda")
     import starneig_amd as S
     from starneig_amd import distributed as D
@@ -29,7 +33,8 @@ def main():
     torch.cuda.synchronize()
     assert rc == 0, rc
     # every rank holds the same assembled result
-    chk = torch.stack([tA.abs().sum(), tQ.abs().sum()]).cpu()
+    chk = torch.stack([tA.abs().sum(), tQ.abs().sum()])
+    chk = chk if backend == "nccl" else chk.cpu()
     ref = chk.clone(); dist.broadcast(ref, src=0)
     assert torch.allclose(chk, ref, rtol=1e-13), (rank, chk, ref)
     if rank == 0:
@@ -41,6 +46,8 @@ def main():
         scale = torch.linalg.norm(tA0[:, :n]).item()
         diff = (tA[:, :n] - tB[:, :n]).abs().max().item() / scale
         assert diff <= 8 * np.sqrt(n) * 2.0 ** -52, diff
+        if backend == "nccl":
+            assert st["collectives"] == "RCCL, called from the library", st["collectives"]
         print(f"DIST-OK world={world} n={n} pw={pw} residual={c['residual_u']:.1f}u "
               f"diff={diff / 2.0**-52:.1f}u collectives={st['collectives']}", flush=True)
     dist.barrier()
@@ -49,7 +56,8 @@ def main():
     rc, real, imag, sst = D.schur_sharded(tA, tQ, n=n)
     torch.cuda.synchronize()
     assert rc == 0, rc
-    chk = torch.stack([tA.abs().sum(), tQ.abs().sum()]).cpu()
+    chk = torch.stack([tA.abs().sum(), tQ.abs().sum()])
+    chk = chk if backend == "nccl" else chk.cpu()
     ref = chk.clone(); dist.broadcast(ref, src=0)
     assert torch.equal(chk, ref), (rank, chk, ref)          # replicas are bit-identical
     if rank == 0:

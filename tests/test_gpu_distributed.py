@@ -22,3 +22,16 @@ def test_sharded_hessenberg_matches_single_gpu(world, n, pw):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DIST-SCHUR-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_sharded_hessenberg_with_the_library_calling_rccl():
+    """One rank on the "nccl" backend: the collectives of the sharded path are issued to RCCL from
+    the library (starneig_amd/csrc/rccl_native.hip) after the communicator passed its self-test
+    (starneig_amd/distributed.py native_rccl); result compared with the single-GPU path."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "tests", "dist_hess_worker.py"), "900", "64", "nccl"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "DIST-OK" in out.stdout and "DIST-SCHUR-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
