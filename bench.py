@@ -509,6 +509,10 @@ def main():
         if world == 1 and (args.cpu_n > 0 or args.cpu_port_n > 0):
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_port_n)
 
+    if sharded:
+        from starneig_amd import distributed as _D
+        torch.cuda.synchronize()
+        _D.shutdown()               # the library's own RCCL communicator, before torch's
     S.node_finalize()
     if sharded:
         dist.destroy_process_group()

@@ -90,6 +90,13 @@ def native_rccl(group=None):
     return False
 
 
+def shutdown():
+    """Destroys the library's RCCL communicator (call before torch.distributed.destroy_process_group)."""
+    if _native["state"]:
+        lib.load().starneig_amd_rccl_finalize()
+    _native["state"] = None
+
+
 class Collectives:
     """Maps the library's (buffer id, offset, count) requests onto torch.distributed calls."""
 

@@ -72,6 +72,7 @@ def main():
         print(f"DIST-SCHUR-OK world={world} n={n} residual={c['residual_u']:.1f}u rows={sst['q_rows']}",
               flush=True)
     dist.barrier()
+    D.shutdown()
     S.node_finalize()
     dist.destroy_process_group()
 
