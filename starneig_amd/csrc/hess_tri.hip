@@ -311,7 +311,18 @@ __global__ __launch_bounds__(64) void ht_rowpass2_kernel(RowPassArgs a)
     if (c >= a.n) return;
     int const istart = a.tri ? std::min(a.n - 1, c + 1) : a.n - 1;       // first rotation of this column
     double carry = (a.tri && istart == c + 1) ? 0.0 : a.M[(size_t)c * a.ld + istart];
-    for (int seg = (istart - 1) / 64; seg >= a.seg_lo; seg--) {
+    int seg = (istart - 1) / 64;
+    for (; seg - 15 >= a.seg_lo; seg -= 16) {               // loads of a batch first (they do not depend on the carry)
+        double b[16], al[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { b[k] = a.beta[(size_t)(seg - k) * a.n + c]; al[k] = a.alpha[seg - k]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            a.beta[(size_t)(seg - k) * a.n + c] = carry;
+            carry = al[k] * carry + b[k];
+        }
+    }
+    for (; seg >= a.seg_lo; seg--) {
         double const b = a.beta[(size_t)seg * a.n + c];
         a.beta[(size_t)seg * a.n + c] = carry;
         carry = a.alpha[seg] * carry + b;
