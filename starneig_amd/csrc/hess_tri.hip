@@ -407,6 +407,41 @@ __global__ __launch_bounds__(64) void ht_colpass_kernel(ColJob j0, ColJob j1, Co
     job.M[(size_t)(t_lo - 1) * job.ld + row] = y;
 }
 
+// The row rotations of TWO consecutive sweeps (a = j-1, b = j) on Q in one pass over its columns: Q is
+// pure HBM traffic here, nothing waits for it, and rotation B_k only needs A_k and A_{k-1} done.
+// Per step k = n-1 .. j+1: A_k on columns (k-1, k), then B_{k+1} on (k, k+1), whose column k+1 is final.
+__global__ __launch_bounds__(64) void ht_qpass2_kernel(double *__restrict__ Q, int ld, int rows, int n, int j,
+    double const *__restrict__ Rca, double const *__restrict__ Rsa,
+    double const *__restrict__ Rcb, double const *__restrict__ Rsb)
+{
+    int const row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    double p = Q[(size_t)(n - 1) * ld + row], q = 0.0;              // column k carried by sweep a, column k+1 by sweep b
+    int k = n - 1;
+    auto step = [&](int kk, double x) {
+        // A_kk on (x = column kk-1, p = column kk); Q takes the row rotations transposed: sgn = -1
+        double const ca = Rca[kk], sa = -Rsa[kk];
+        double const colk = sa * x + ca * p;                        // column kk, final for sweep a
+        p = ca * x - sa * p;
+        if (kk + 1 <= n - 1) {                                      // B_{kk+1} on (column kk, column kk+1)
+            double const cb = Rcb[kk + 1], sb = -Rsb[kk + 1];
+            Q[(size_t)(kk + 1) * ld + row] = sb * colk + cb * q;
+            q = cb * colk - sb * q;
+        } else
+            q = colk;
+    };
+    for (; k - 15 >= j + 1; k -= 16) {
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = Q[(size_t)(k - i - 1) * ld + row];
+#pragma unroll
+        for (int i = 0; i < 16; i++) step(k - i, x[i]);
+    }
+    for (; k >= j + 1; k--) step(k, Q[(size_t)(k - 1) * ld + row]);
+    Q[(size_t)(j + 1) * ld + row] = q;                              // column j+1 carried by sweep b
+    Q[(size_t)j * ld + row] = p;                                    // column j carried by sweep a
+}
+
 // The same column rotations for the rows of B that the NEXT chain launch waits for: the plain kernel
 // above spends one memory latency per batch of columns on every row (50 us for 512 rotations however
 // few rows there are).  Here a workgroup stages 32 rows x all columns of the group in LDS with every
@@ -844,17 +879,22 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     for (int j = 0; j + 2 < n; j++) {
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));          // A, B, Z of the previous sweep complete
         ws.Rc = ws.Rc2[j & 1]; ws.Rs = ws.Rs2[j & 1];               // (Q is still taking the rotations of sweep j-1)
-        if (j >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[j & 1], 0));
+        if (j >= 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));  // the last pass over Q has read both buffers
         hipLaunchKernelGGL(ht_scan_kernel, dim3(1), dim3(1024), 0, s, n, j, dA, ldA, ws.Rc, ws.Rs);
         SN_HIP_CHECK(hipEventRecord(ws.e_scan, s));
         row_pass(s, ws, 0, n, j, 1, dB, ldB);
         SN_HIP_CHECK(hipStreamWaitEvent(side, ws.e_scan, 0));
         row_pass(side, ws, 1, n, j, 0, dA, ldA);
-        if (dQ) {
+        if (dQ && ((j & 1) || j + 3 >= n)) {
+            // Q takes the row rotations of two sweeps per pass (odd j: sweeps j-1 and j); a last even sweep alone
             SN_HIP_CHECK(hipStreamWaitEvent(ws.qstream, ws.e_scan, 0));
-            hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 1), dim3(64), 0, ws.qstream,
-                ColJob{dQ, ldQ, n}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, n - 1, j + 2, ws.Rc, ws.Rs, -1.0);
-            SN_HIP_CHECK(hipEventRecord(ws.e_q[j & 1], ws.qstream));
+            if (j & 1)
+                hipLaunchKernelGGL(ht_qpass2_kernel, dim3(divceil(n, 64)), dim3(64), 0, ws.qstream, dQ, ldQ, n, n, j,
+                    ws.Rc2[0], ws.Rs2[0], ws.Rc2[1], ws.Rs2[1]);
+            else
+                hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 1), dim3(64), 0, ws.qstream,
+                    ColJob{dQ, ldQ, n}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, n - 1, j + 2, ws.Rc, ws.Rs, -1.0);
+            SN_HIP_CHECK(hipEventRecord(ws.e_q[0], ws.qstream));
         }
         int gi = 0;
         for (int g1 = n; g1 > j + 2; gi++) {
@@ -880,7 +920,7 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
         rotations += 2.0 * (n - j - 2);
     }
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));
-    if (dQ && n > 2) { SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0)); if (n > 3) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0)); }
+    if (dQ && n > 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, -1);
     int chain_err = 0;
     SN_HIP_CHECK(hipMemcpyAsync(&chain_err, ws.amax + 1, sizeof(int), hipMemcpyDeviceToHost, s));
