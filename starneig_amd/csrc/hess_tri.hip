@@ -407,24 +407,26 @@ __global__ __launch_bounds__(64) void ht_colpass_kernel(ColJob j0, ColJob j1, Co
     job.M[(size_t)(t_lo - 1) * job.ld + row] = y;
 }
 
-// The row rotations of TWO consecutive sweeps (a = j-1, b = j) on Q in one pass over its columns: Q is
-// pure HBM traffic here, nothing waits for it, and rotation B_k only needs A_k and A_{k-1} done.
+// The rotations of TWO consecutive sweeps (a = j-1, b = j) on Q (row rotations) or Z (column rotations) in
+// one pass over the columns: Q and Z are pure HBM traffic here, nothing waits for them, and rotation B_k
+// only needs A_k and A_{k-1} done.
 // Per step k = n-1 .. j+1: A_k on columns (k-1, k), then B_{k+1} on (k, k+1), whose column k+1 is final.
 __global__ __launch_bounds__(64) void ht_qpass2_kernel(double *__restrict__ Q, int ld, int rows, int n, int j,
     double const *__restrict__ Rca, double const *__restrict__ Rsa,
-    double const *__restrict__ Rcb, double const *__restrict__ Rsb)
+    double const *__restrict__ Rcb, double const *__restrict__ Rsb, double sgn)
 {
     int const row = blockIdx.x * 64 + threadIdx.x;
     if (row >= rows) return;
     double p = Q[(size_t)(n - 1) * ld + row], q = 0.0;              // column k carried by sweep a, column k+1 by sweep b
     int k = n - 1;
     auto step = [&](int kk, double x) {
-        // A_kk on (x = column kk-1, p = column kk); Q takes the row rotations transposed: sgn = -1
-        double const ca = Rca[kk], sa = -Rsa[kk];
+        // A_kk on (x = column kk-1, p = column kk); Q takes the row rotations transposed (sgn = -1),
+        // Z the column rotations as they are (sgn = +1)
+        double const ca = Rca[kk], sa = sgn * Rsa[kk];
         double const colk = sa * x + ca * p;                        // column kk, final for sweep a
         p = ca * x - sa * p;
         if (kk + 1 <= n - 1) {                                      // B_{kk+1} on (column kk, column kk+1)
-            double const cb = Rcb[kk + 1], sb = -Rsb[kk + 1];
+            double const cb = Rcb[kk + 1], sb = sgn * Rsb[kk + 1];
             Q[(size_t)(kk + 1) * ld + row] = sb * colk + cb * q;
             q = cb * colk - sb * q;
         } else
@@ -754,12 +756,14 @@ struct HtWorkspace {
     int n = 0, ldp = 0;
     double *Vp = nullptr, *VT = nullptr, *W = nullptr, *G = nullptr, *T = nullptr, *tau = nullptr;
     double *part[2] = {nullptr, nullptr}, *prow[2] = {nullptr, nullptr};
-    double *Rc2[2] = {nullptr, nullptr}, *Rs2[2] = {nullptr, nullptr}, *Rc = nullptr, *Rs = nullptr, *Cc = nullptr, *Cs = nullptr;
+    double *Rc2[2] = {nullptr, nullptr}, *Rs2[2] = {nullptr, nullptr}, *Rc = nullptr, *Rs = nullptr;
+    double *Cc2[3] = {nullptr, nullptr, nullptr}, *Cs2[3] = {nullptr, nullptr, nullptr}, *Cc = nullptr, *Cs = nullptr;
     unsigned long long *amax = nullptr;
     double *rp_beta[2] = {nullptr, nullptr}, *rp_up[2] = {nullptr, nullptr}, *rp_alpha[2] = {nullptr, nullptr};   // row pass: [0] B, [1] A
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     hipStream_t side = nullptr, qstream = nullptr;
-    hipEvent_t e_scan = nullptr, e_side = nullptr, e_q[2] = {nullptr, nullptr};
+    hipEvent_t e_scan = nullptr, e_side = nullptr, e_q[2] = {nullptr, nullptr};   // e_q[0]: last pass over Q, e_q[1]: over Z
+    hipEvent_t e_cdone = nullptr;
     std::vector<hipEvent_t> e_chain;                    // one per diagonal group of a sweep
     void ensure(int n_)
     {
@@ -770,6 +774,7 @@ struct HtWorkspace {
             SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
             SN_HIP_CHECK(hipStreamCreateWithPriority(&qstream, hipStreamNonBlocking, lo));
             for (auto &e : e_q) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            SN_HIP_CHECK(hipEventCreateWithFlags(&e_cdone, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_scan, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_side, hipEventDisableTiming));
         }
@@ -787,7 +792,7 @@ struct HtWorkspace {
         alloc(G, QNB * QNB); alloc(T, QNB * QNB); alloc(tau, QNB);
         for (int b = 0; b < 2; b++) { alloc(part[b], (size_t)divceil(n, QROWS) * QP); alloc(prow[b], QNB); }
         for (int b = 0; b < 2; b++) { alloc(Rc2[b], n); alloc(Rs2[b], n); }
-        alloc(Cc, n); alloc(Cs, n);
+        for (int b = 0; b < 3; b++) { alloc(Cc2[b], n); alloc(Cs2[b], n); }
         if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 16));       // [0] max |b|, [1] error flag of the chain kernels
         for (int b = 0; b < 2; b++) {
             alloc(rp_beta[b], (size_t)divceil(n, 64) * n); alloc(rp_up[b], (size_t)divceil(n, 64) * n); alloc(rp_alpha[b], divceil(n, 64));
@@ -795,7 +800,7 @@ struct HtWorkspace {
     }
     void release_buffers()
     {
-        double **all[] = {&Vp, &VT, &W, &G, &T, &tau, &part[0], &part[1], &prow[0], &prow[1], &Rc2[0], &Rc2[1], &Rs2[0], &Rs2[1], &Cc, &Cs,
+        double **all[] = {&Vp, &VT, &W, &G, &T, &tau, &part[0], &part[1], &prow[0], &prow[1], &Rc2[0], &Rc2[1], &Rs2[0], &Rs2[1], &Cc2[0], &Cc2[1], &Cc2[2], &Cs2[0], &Cs2[1], &Cs2[2],
             &rp_beta[0], &rp_beta[1], &rp_up[0], &rp_up[1], &rp_alpha[0], &rp_alpha[1]};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
@@ -878,7 +883,8 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     SN_HIP_CHECK(hipEventRecord(ws.e_side, s));
     for (int j = 0; j + 2 < n; j++) {
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));          // A, B, Z of the previous sweep complete
-        ws.Rc = ws.Rc2[j & 1]; ws.Rs = ws.Rs2[j & 1];               // (Q is still taking the rotations of sweep j-1)
+        ws.Rc = ws.Rc2[j & 1]; ws.Rs = ws.Rs2[j & 1];               // (Q and Z take the rotations of two sweeps per pass)
+        ws.Cc = ws.Cc2[j % 3]; ws.Cs = ws.Cs2[j % 3];               // three buffers: the pass over Z that reads sweeps j-2, j-1 may still run
         if (j >= 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));  // the last pass over Q has read both buffers
         hipLaunchKernelGGL(ht_scan_kernel, dim3(1), dim3(1024), 0, s, n, j, dA, ldA, ws.Rc, ws.Rs);
         SN_HIP_CHECK(hipEventRecord(ws.e_scan, s));
@@ -890,12 +896,13 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
             SN_HIP_CHECK(hipStreamWaitEvent(ws.qstream, ws.e_scan, 0));
             if (j & 1)
                 hipLaunchKernelGGL(ht_qpass2_kernel, dim3(divceil(n, 64)), dim3(64), 0, ws.qstream, dQ, ldQ, n, n, j,
-                    ws.Rc2[0], ws.Rs2[0], ws.Rc2[1], ws.Rs2[1]);
+                    ws.Rc2[0], ws.Rs2[0], ws.Rc2[1], ws.Rs2[1], -1.0);
             else
                 hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 1), dim3(64), 0, ws.qstream,
                     ColJob{dQ, ldQ, n}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, n - 1, j + 2, ws.Rc, ws.Rs, -1.0);
             SN_HIP_CHECK(hipEventRecord(ws.e_q[0], ws.qstream));
         }
+        if (dZ && (j & 1) && j >= 3) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0));   // the pass over Z launched after sweep j-2 read this buffer
         int gi = 0;
         for (int g1 = n; g1 > j + 2; gi++) {
             int const g0 = std::max(0, (g1 - 1) / HGR * HGR);
@@ -912,15 +919,28 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
                 hipLaunchKernelGGL(ht_colpass_lds_kernel, dim3(divceil(near_lo, CL_ROWS)), dim3(256), CL_LDS_BYTES, s,
                     dB, ldB, near_lo, t_hi, t_lo, ws.Cc, ws.Cs);
             SN_HIP_CHECK(hipStreamWaitEvent(side, ws.e_chain[gi], 0));
-            hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 2), dim3(64), 0, side,
-                ColJob{dA, ldA, n}, ColJob{dZ, ldZ, dZ ? n : 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
+            hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 1), dim3(64), 0, side,
+                ColJob{dA, ldA, n}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, t_hi, t_lo, ws.Cc, ws.Cs, 1.0);
             g1 = g0;
         }
         SN_HIP_CHECK(hipEventRecord(ws.e_side, side));
+        if (dZ && ((j & 1) || j + 3 >= n)) {
+            // Z takes the column rotations of two sweeps per pass, like Q the row rotations
+            SN_HIP_CHECK(hipEventRecord(ws.e_cdone, s));
+            SN_HIP_CHECK(hipStreamWaitEvent(ws.qstream, ws.e_cdone, 0));
+            if (j & 1)
+                hipLaunchKernelGGL(ht_qpass2_kernel, dim3(divceil(n, 64)), dim3(64), 0, ws.qstream, dZ, ldZ, n, n, j,
+                    ws.Cc2[(j - 1) % 3], ws.Cs2[(j - 1) % 3], ws.Cc2[j % 3], ws.Cs2[j % 3], 1.0);
+            else
+                hipLaunchKernelGGL(ht_colpass_kernel, dim3(divceil(n, 64), 1), dim3(64), 0, ws.qstream,
+                    ColJob{dZ, ldZ, n}, ColJob{nullptr, 0, 0}, ColJob{nullptr, 0, 0}, n - 1, j + 2, ws.Cc, ws.Cs, 1.0);
+            SN_HIP_CHECK(hipEventRecord(ws.e_q[1], ws.qstream));
+        }
         rotations += 2.0 * (n - j - 2);
     }
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));
     if (dQ && n > 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));
+    if (dZ && n > 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0));
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, -1);
     int chain_err = 0;
     SN_HIP_CHECK(hipMemcpyAsync(&chain_err, ws.amax + 1, sizeof(int), hipMemcpyDeviceToHost, s));
