@@ -761,7 +761,7 @@ struct HtWorkspace {
     unsigned long long *amax = nullptr;
     double *rp_beta[2] = {nullptr, nullptr}, *rp_up[2] = {nullptr, nullptr}, *rp_alpha[2] = {nullptr, nullptr};   // row pass: [0] B, [1] A
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    hipStream_t side = nullptr, qstream = nullptr;
+    hipStream_t main = nullptr, side = nullptr, qstream = nullptr;
     hipEvent_t e_scan = nullptr, e_side = nullptr, e_q[2] = {nullptr, nullptr};   // e_q[0]: last pass over Q, e_q[1]: over Z
     hipEvent_t e_cdone = nullptr;
     std::vector<hipEvent_t> e_chain;                    // one per diagonal group of a sweep
@@ -771,6 +771,7 @@ struct HtWorkspace {
             for (auto &e : ev) SN_HIP_CHECK(hipEventCreate(&e));
             int lo = 0, hi = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = least urgent
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, hi));
             SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
             SN_HIP_CHECK(hipStreamCreateWithPriority(&qstream, hipStreamNonBlocking, lo));
             for (auto &e : e_q) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -856,12 +857,17 @@ void hessenberg_triangular_release_workspace() { g_ht.release_buffers(); }
 // (dA, dB) general -> (H, T) upper Hessenberg / upper triangular with dQ <- dQ*U1, dZ <- dZ*U2
 // (dQ, dZ may be NULL).  stats (may be NULL): [0] total ms, [1] QR step ms, [2] rotation step ms,
 // [3] executed GEMM flops, [4] rotations.
-int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,
+int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA, double *dB, int ldB,
     double *dQ, int ldQ, double *dZ, int ldZ, double *stats)
 {
     HtWorkspace &ws = g_ht;
     ws.ensure(n);
     double flops = 0.0, rotations = 0.0;
+    // the dependent path runs on a stream of the highest priority: its small kernels (one workgroup
+    // with 100 KB of LDS) must not queue behind the thousands of workgroups of the streaming passes
+    hipStream_t const s = ws.main;
+    SN_HIP_CHECK(hipEventRecord(ws.e_cdone, caller));
+    SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_cdone, 0));
     SN_HIP_CHECK(hipEventRecord(ws.ev[0], s));
     SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 16, s));
     hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dB, ldB, ws.amax);
@@ -945,6 +951,7 @@ int hessenberg_triangular_device(hipStream_t s, int n, double *dA, int ldA, doub
     int chain_err = 0;
     SN_HIP_CHECK(hipMemcpyAsync(&chain_err, ws.amax + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SN_HIP_CHECK(hipEventRecord(ws.ev[2], s));
+    SN_HIP_CHECK(hipStreamWaitEvent(caller, ws.ev[2], 0));
     SN_HIP_CHECK(hipStreamSynchronize(s));
     if (stats) {
         float t01 = 0.f, t12 = 0.f;
