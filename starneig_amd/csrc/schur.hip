@@ -45,6 +45,7 @@ constexpr int LDW = WS_MAX + 1;     // odd leading dimension: conflict-free row 
 constexpr int CHASE_THREADS = 1024; // 16 waves share one window (512 threads: 15 % slower)
 constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
+constexpr int UPDATE_LDS_BYTES_R64 = GemmCfg<64, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_P = UPDATE_LDS_BYTES_L > UPDATE_LDS_BYTES_R ? UPDATE_LDS_BYTES_L : UPDATE_LDS_BYTES_R;
 constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // W, U, two reflector buffers
 
@@ -274,7 +275,7 @@ void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ld
 // (MODE 0) or row (MODE 1) range of a launch.
 // One workgroup owns all w <= WS_MAX = 96 rows (columns) of its tile (96-wide MFMA tiles: no padding) and reads its whole operand
 // panel before the epilogue writes, so the update is done in place.
-template <int MODE>
+template <int MODE, int RBM = 128>
 __device__ __forceinline__
 void schur_update_body(SweepStep const &step, double *__restrict__ H, int ldH,
     double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U, int r0, int r1, int bx, int by)
@@ -304,18 +305,18 @@ void schur_update_body(SweepStep const &step, double *__restrict__ H, int ldH,
         double *X = H + (size_t)lo * ldH + rbeg;
         gemm_tile<128, WS_MAX, 16, false, false>(rows, w, w, 1.0, X, ldH, Uk, WS_MAX, 0.0, X, ldH, bx, 0);
     } else {
-        if (bx * 128 >= n) return;
+        if (bx * RBM >= n) return;
         double *X = Q + (size_t)lo * ldQ;
-        gemm_tile<128, WS_MAX, 16, false, false>(n, w, w, 1.0, X, ldQ, Uk, WS_MAX, 0.0, X, ldQ, bx, 0);
+        gemm_tile<RBM, WS_MAX, 16, false, false>(n, w, w, 1.0, X, ldQ, Uk, WS_MAX, 0.0, X, ldQ, bx, 0);
     }
 }
 
-template <int MODE>
+template <int MODE, int RBM = 128>
 __global__ __launch_bounds__(256, 2)
 void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U, int r0, int r1)
 {
-    schur_update_body<MODE>(step, H, ldH, Q, ldQ, n, U, r0, r1, blockIdx.x, blockIdx.y);
+    schur_update_body<MODE, RBM>(step, H, ldH, Q, ldQ, n, U, r0, r1, blockIdx.x, blockIdx.y);
 }
 
 // The LAZY far-left (blockIdx.z = 0, columns [c0, c1) right of ihi) and right (blockIdx.z = 1,
@@ -446,6 +447,8 @@ struct SchurWorkspace {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&z_done[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&zh_done[k], hipEventDisableTiming));
             }
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<3, 64>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R64));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<3>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_pair_kernel,
@@ -825,6 +828,7 @@ struct Driver {
                     dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
                     UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
             if (Q)
+                // (64-row tiles reach 13 % more of the HBM rate alone, scratch/update_bench.py, but change nothing in situ)
                 hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(nq, 128), ntasks),
                     dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, nq, Ubuf, 0, nq);
             ws.slot_flush[it.ev] = ws.flush_total;
@@ -1383,4 +1387,41 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
     }
     SN_HIP_CHECK(hipFree(H0)); SN_HIP_CHECK(hipFree(H)); SN_HIP_CHECK(hipFree(U)); SN_HIP_CHECK(hipFree(sr)); SN_HIP_CHECK(hipFree(si));
     return total / reps * 1e3;      // microseconds
+}
+
+// ---- measurement hook (scratch/update_bench.py): average duration of one lazy Q update launch
+// (schur_update_kernel<3>: Q(:, window) <- Q(:, window) U for `chains` windows) on an nq-row Q, alone on the GPU
+extern "C" __attribute__((visibility("default")))
+double sn_internal_qupdate_bench(int nq, int chains, int reps, int rbm)
+{
+    using namespace sn;
+    int const ws_ = WS_MAX, nbc = NB_MAX, adv = ws_ - 1 - 3 * nbc, gap = divceil(ws_ + adv, adv);
+    int const n = ws_ + adv * (gap * (chains - 1) + 4) + 200, ld = (int)roundup(nq, 16);
+    double *Q, *U;
+    SN_HIP_CHECK(hipMalloc((void **)&Q, (size_t)ld * n * 8));
+    SN_HIP_CHECK(hipMalloc((void **)&U, (size_t)chains * WS_MAX * WS_MAX * 8));
+    lcg_fill(nullptr, nq, n, 7u, 1, Q, ld);
+    for (int k = 0; k < chains; k++) set_matrix(nullptr, WS_MAX, WS_MAX, 0.0, 1.0, U + (size_t)k * WS_MAX * WS_MAX, WS_MAX);
+    SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
+    int const spc = divceil(n - ws_, adv) + 1;
+    SweepStep step{0, n, ws_, nbc, adv, gap, nbc * chains, spc, 0, 0, 0};
+    step.t = gap * (chains - 1) + 2; step.cmin = 0; step.ntasks = chains;
+    constexpr int lds64 = GemmCfg<64, WS_MAX, 16, false, false>::LDS_BYTES;
+    hipEvent_t e0, e1; SN_HIP_CHECK(hipEventCreate(&e0)); SN_HIP_CHECK(hipEventCreate(&e1));
+    double total = 0.0;
+    for (int r = 0; r < reps + 1; r++) {
+        SN_HIP_CHECK(hipEventRecord(e0, nullptr));
+        if (rbm == 64)
+            hipLaunchKernelGGL((schur_update_kernel<3, 64>), dim3(divceil(nq, 64), chains), dim3(256),
+                lds64, nullptr, step, (double *)nullptr, 0, Q, ld, nq, U, 0, nq);
+        else
+            hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(nq, 128), chains), dim3(256), UPDATE_LDS_BYTES_R, nullptr,
+                step, (double *)nullptr, 0, Q, ld, nq, U, 0, nq);
+        SN_HIP_CHECK(hipEventRecord(e1, nullptr));
+        SN_HIP_CHECK(hipEventSynchronize(e1));
+        float ms; SN_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    SN_HIP_CHECK(hipFree(Q)); SN_HIP_CHECK(hipFree(U));
+    return total / reps * 1e3;
 }
