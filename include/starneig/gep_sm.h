@@ -36,8 +36,10 @@ starneig_error_t starneig_GEP_SM_Reduce(
  * non-negative there), Q <- Q*U1, Z <- Z*U2 so that Q (S,T) Z^T = Q_in (H,R) Z_in^T.
  * The eigenvalues are (real[i] + i*imag[i]) / beta[i] in diagonal order.
  * Errors: n<1 -> -1, H NULL -> -2, ldH<n -> -3, R NULL -> -4, ldR<n -> -5, Q NULL -> -6,
- * ldQ<n -> -7, Z NULL -> -8, ldZ<n -> -9 (schur/interface.c:283-291), real/imag/beta
- * NULL -> -10/-11/-12; STARNEIG_NOT_INITIALIZED; STARNEIG_DID_NOT_CONVERGE. */
+ * ldQ<n -> -7, Z NULL -> -8, ldZ<n -> -9 (schur/interface.c:283-291; the checks stop there:
+ * NULL real / imag / beta mean "eigenvalues not extracted", as in the reference);
+ * STARNEIG_NOT_INITIALIZED; STARNEIG_DID_NOT_CONVERGE.  conf->right_threshold is accepted,
+ * range-checked and not used. */
 starneig_error_t starneig_GEP_SM_Schur(
     int n, double H[], int ldH, double R[], int ldR,
     double Q[], int ldQ, double Z[], int ldZ,

@@ -47,8 +47,6 @@ starneig_error_t starneig_SEP_SM_Select(
     int (*predicate)(double real, double imag, void *arg), void *arg,
     int selected[], int *num_selected);
 
-/* Hessenberg followed by Schur (the reordering leg of common/combined.c:46-98
- * is outside this path: predicate must be NULL). */
 /* reference sep_sm.h:174-179, :474-480 (reorder/interface.c:210-263): moves the selected
  * eigenvalues (selected[i] != 0; a 2x2 block is selected as a whole) to the top-left corner of
  * the Schur form, S <- U^T S U, Q <- Q U; on exit selected[] marks the final positions of the
@@ -62,6 +60,10 @@ starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
     struct starneig_reorder_conf *conf, int n, int selected[],
     double S[], int ldS, double Q[], int ldQ, double real[], double imag[]);
 
+/* reference sep_sm.h:232-240 (common/combined.c:46-98): Hessenberg + Schur; with a predicate
+ * also Select + ReorderSchur, the sequence of examples/sep_sm_full_chain.c:88-121 (selected /
+ * num_selected are then written).  predicate may be NULL (no reordering).  Errors: n<1 -> -1,
+ * A NULL -> -2, ldA<n -> -3, Q NULL -> -4, ldQ<n -> -5. */
 starneig_error_t starneig_SEP_SM_Reduce(
     int n, double A[], int ldA, double Q[], int ldQ,
     double real[], double imag[],

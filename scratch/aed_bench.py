@@ -4,7 +4,7 @@ import numpy as np
 import starneig_amd as S, oracle as O
 sys.path.insert(0, "tests")
 dp = C.POINTER(C.c_double)
-L = S.lib.load()
+L = S.lib.load_test_hooks()
 L.sn_internal_aed_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.POINTER(C.c_int)]
 def P(a): return a.ctypes.data_as(dp)
 for nw in (128, 192, 256, 384):

@@ -4,7 +4,7 @@ import torch
 import starneig_amd as S
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
 S.node_init(1, 1, S.NO_MESSAGES)
-L = S.lib.load()
+L = S.lib.load_test_hooks()
 L.sn_internal_chase_bench.restype = C.c_double
 L.sn_internal_chase_bench.argtypes = [C.c_int, C.c_int, C.c_int]
 for chains in (1, 29):

@@ -5,7 +5,7 @@ import torch
 import starneig_amd as S
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
 S.node_init(1, 1, S.NO_MESSAGES)
-L = S.lib.load()
+L = S.lib.load_test_hooks()
 L.sn_internal_ht_chain_bench.restype = C.c_double
 L.sn_internal_ht_chain_bench.argtypes = [C.c_int, C.c_int]
 names = {0: "4 group waves + 12 followers", 1: "4 group waves, no followers", 2: "4 + 4 followers", 3: "no loads", 4: "no result stores",

@@ -5,7 +5,7 @@ import torch
 import starneig_amd as S
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
 S.node_init(1, 1, S.NO_MESSAGES)
-L = S.lib.load()
+L = S.lib.load_test_hooks()
 L.sn_internal_qupdate_bench.restype = C.c_double
 L.sn_internal_qupdate_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
 for rbm, chains in [(r, c) for r in (128, 64) for c in (1, 4, 10, 20)]:

@@ -5,12 +5,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstarneig_amd.so")
+TEST_LIB = os.path.join(HERE, "libstarneig_amd_test.so")     # product objects + test hooks
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(TEST_LIB):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(TEST_LIB))
     for f in os.listdir(CSRC):
         if f.endswith((".hip", ".h", "Makefile")) and os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
@@ -22,7 +23,7 @@ def needs_build():
     return False
 
 
-def build(force=False, jobs=4):
+def build(force=False, jobs=6):
     if force or needs_build():
         subprocess.check_call(["make", "-C", CSRC, "-j", str(jobs)] + (["-B"] if force else []))
     return LIB

@@ -969,6 +969,7 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
 
 } // namespace sn
 
+#ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- measurement hook (NOT part of the public C-ABI; scratch/ht_chain_bench.py): average duration
 // of one ht_chain_kernel launch on the bottom group (256 rotations) of a random upper Hessenberg B
 extern "C" __attribute__((visibility("default")))
@@ -1018,3 +1019,4 @@ double sn_internal_ht_chain_bench(int variant, int reps)
     SN_HIP_CHECK(hipFree(B0)); SN_HIP_CHECK(hipFree(B)); SN_HIP_CHECK(hipFree(Cc)); SN_HIP_CHECK(hipFree(Cs)); SN_HIP_CHECK(hipFree(ts));
     return total / reps * 1e3;
 }
+#endif  // SN_TEST_HOOKS

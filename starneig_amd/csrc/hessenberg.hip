@@ -21,6 +21,7 @@
 // All panel matrices (P,V,VT,Y) are indexed by GLOBAL row so that the 16-byte row
 // pairs of the gemv stay aligned for every panel offset.
 #include "common.h"
+#include "tuning.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -542,9 +543,9 @@ static void choose_split(int m_rows, int ncols, int *nsplit, int *cps)
     // ~4 streaming workgroups per CU (measured at n = 20000: 4.70 / 4.71 / 4.80 / 4.9 s for 512 /
     // 1024 / 1280 / 1792 workgroups); together with the shadow blocks of the launch they must all
     // be resident at once (8 workgroups of 256 threads per CU at 64 VGPRs)
-    static int const target_wgs = getenv("SN_HESS_WGS") ? atoi(getenv("SN_HESS_WGS")) : 1024;
+    int const target_wgs = tuning().hess_wgs;
     int want = std::max(1, target_wgs / row_tiles);
-    static int const max_split = getenv("SN_HESS_MAXSPLIT") ? atoi(getenv("SN_HESS_MAXSPLIT")) : 32;
+    int const max_split = tuning().hess_max_split;
     int s = std::min({want, max_split, MAX_SPLIT, std::max(1, ncols / 16)});
     int c = divceil(ncols, s);
     c = (c + 15) / 16 * 16;
@@ -575,7 +576,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
     // profiling aid: stop after k panels (PMC runs cannot take 60 k dispatches); the result
     // is then a partial reduction and must not be used
-    int const max_panels = getenv("SN_HESS_MAX_PANELS") ? atoi(getenv("SN_HESS_MAX_PANELS")) : 1 << 30;
+    int const max_panels = tuning().hess_max_panels;
     int pcount = 0;
     for (int i = begin; i < end - 1 && pcount < max_panels; i += panel_width, pcount++) {
         int const nb = std::min(panel_width, end - i - 1);
@@ -617,7 +618,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             // once the trailing matrix fits the 256 MB Infinity Cache the next column re-reads part of
             // it from there: temporal loads (the streaming, non-temporal ones bypass the caches).
             // Measured: 4 % on the whole reduction at n = 6000, nothing at n = 20000.
-            static long const cache_bytes = (getenv("SN_HESS_CACHE_MB") ? atol(getenv("SN_HESS_CACHE_MB")) : 256L) << 20;
+            long const cache_bytes = tuning().hess_cache_mb << 20;
             if (aligned && (long)m * ncols * 8 <= cache_bytes)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, false>), grid, dim3(256), 0, s,
                     dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
@@ -668,7 +669,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         SN_HIP_CHECK(hipEventRecord(ws.panel_done[buf], s));
 
         // ---- non-critical updates on the side stream (core.c:321-340) ----
-        hipStream_t q = getenv("SN_HESS_NOSIDE") ? s : ws.side;
+        hipStream_t q = tuning().hess_noside ? s : ws.side;
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
         if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(128) void reorder_copy_windows_kernel(WinMeta const
     if (dir == 0) *t = *g; else *g = *t;
 }
 
-// a few host threads that reorder the windows of one round side by side
+// a few host threads that reorder the windows of one round side by side.  A round's state (job,
+// total, next) is only ever written while no worker is inside work(): run() returns when every
+// index is done AND every worker that joined the round has left it (`active`), so a worker that
+// fetched a surplus index late cannot meet the next round's counters.
 class WindowPool {
 public:
     explicit WindowPool(int threads)
@@ -62,30 +65,45 @@ public:
     template <typename F> void run(int count, F const &f)
     {
         if (workers.empty() || count == 1) { for (int k = 0; k < count; k++) f(k); return; }
-        job = [&f](int k) { f(k); };
-        { std::lock_guard<std::mutex> l(m); total = count; next.store(0); done = 0; round++; }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = [&f](int k) { f(k); };
+            total = count; next.store(0); done = 0; round++;
+        }
         cv.notify_all();
-        work();                                                 // the caller takes its share
+        work(count);                                            // the caller takes its share
         std::unique_lock<std::mutex> l(m);
-        cv_done.wait(l, [&] { return done == total; });
+        cv_done.wait(l, [&] { return done >= total && active == 0; });
+        total = 0;          // a worker that wakes up from here on has nothing to join
     }
 private:
-    void work()
+    void work(int total_)
     {
         int mine = 0;
         for (;;) {
             int const k = next.fetch_add(1);
-            if (k >= total) break;
+            if (k >= total_) break;
             job(k); mine++;
         }
-        if (mine) { std::lock_guard<std::mutex> l(m); done += mine; if (done == total) cv_done.notify_all(); }
+        std::lock_guard<std::mutex> l(m);
+        done += mine;
     }
     void loop()
     {
         long seen = 0;
         for (;;) {
-            { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return round != seen; }); seen = round; if (quit) return; }
-            work();
+            int total_;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return round != seen; });
+                seen = round;
+                if (quit) return;
+                if (total == 0) continue;                       // the round ended before this thread woke up
+                total_ = total; active++;
+            }
+            work(total_);
+            { std::lock_guard<std::mutex> l(m); active--; }
+            cv_done.notify_all();
         }
     }
     std::vector<std::thread> workers;
@@ -93,7 +111,7 @@ private:
     std::condition_variable cv, cv_done;
     std::function<void(int)> job;
     std::atomic<int> next{0};
-    int total = 0, done = 0;
+    int total = 0, done = 0, active = 0;
     long round = 0;
     bool quit = false;
 };
@@ -202,7 +220,9 @@ int reorder_schur_device(hipStream_t caller, int n, int *selected, double *dS, i
             while (we < n && we - f < W) {
                 int const bs = is_pair(we) ? 2 : 1;
                 if (we + bs - f > W) break;
-                if (sel[we]) { if (cnt + bs > kmax) break; cnt += bs; }
+                // (the first selected block of a window is always admitted: with values_per_chain = 1 a
+                // selected 2x2 block would otherwise never move and the round loop never end)
+                if (sel[we]) { if (cnt > 0 && cnt + bs > kmax) break; cnt += bs; }
                 we += bs;
             }
             while (we > f && !sel[we - 1]) we -= (we - 2 >= f && is_pair(we - 2)) ? 2 : 1;   // unselected rows at the bottom

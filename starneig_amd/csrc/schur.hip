@@ -24,6 +24,7 @@
 #include "schur_host.h"
 #include "dgemm_tile.h"
 #include "schur_common.h"
+#include "tuning.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -249,6 +250,7 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
 {
     schur_chase_body<0>(step, H, ldH, Uout, sr, si);
 }
+#ifdef SN_TEST_HOOKS
 template <int DBG>
 __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ldH,
@@ -256,6 +258,7 @@ void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ld
 {
     schur_chase_body<DBG>(step, H, ldH, Uout, sr, si);
 }
+#endif
 
 // Off-diagonal updates of all chains of one step (row S3).
 //   MODE 2 ("near"): H(win, next `adv` columns right of win) <- U^T .  -- the only part of the
@@ -532,7 +535,7 @@ struct Driver {
     // to the timely zone must first see the lazy updates issued so far.
     void set_guard_row(int r1)
     {
-        static bool const norows = getenv("SN_SCHUR_NOLAZYROWS") != nullptr;   // debugging aid
+        bool const norows = tuning().schur_nolazyrows;   // debugging aid
         r1 = norows ? 0 : std::max(0, r1);
         if (r1 < ws.guard_row) { wait_lazy_h(); prof_guard_moves++; }
         ws.guard_row = r1;
@@ -855,7 +858,7 @@ struct Driver {
     double sweep_flops = 0.0; int sweep_launches = 0;
     int spw_cap = -1;           // conf->shifts_per_window (process_args.c:418-437)
     long chain_passes = 0;      // chains over all sweeps: the rounding error grows like its square root
-    int lazy_batch = getenv("SN_SCHUR_LAZY_BATCH") ? atoi(getenv("SN_SCHUR_LAZY_BATCH")) : 32;
+    int lazy_batch = tuning().schur_lazy_batch;
 
     void sweep_begin(int ilo, int ihi, int nshifts, double const *sr, double const *si)
     {
@@ -1070,7 +1073,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         bool on;
         explicit HelperSession(bool o) : on(o) { if (on) host::helper_session(true); }
         ~HelperSession() { if (on) host::helper_session(false); }
-    } helper_session(level == 0 && prm.host_threads >= 3 && getenv("SN_SCHUR_HELPERS") != nullptr);
+    } helper_session(level == 0 && prm.host_threads >= 3 && tuning().schur_helpers);
 
     SchurWorkspace &ws = g_sws[level];
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});
@@ -1085,7 +1088,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // the residual is 260 / 440 / 780 u at multiplicity 1 / 4 / 8) and buy little where sweeps are
     // short anyway, so the multiplicity grows with the size: 2 below n = 4000, 4 below 12000, 8
     // above.  SN_SCHUR_REUSE=k overrides.
-    static int const reuse_env = getenv("SN_SCHUR_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_SCHUR_REUSE")))) : 0;
+    int const reuse_env = tuning().schur_reuse;
     int const reuse = reuse_env ? reuse_env : (n < 4000 ? 2 : (n < 12000 ? 4 : 8));
     ws.ensure(n, wmax, divceil(reuse * (ns_conf / 2), NB_MAX) + 2);
     ws.guard_row = 0;
@@ -1112,7 +1115,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // by one AED chain -- measured: no effect on the number of sweeps) and runs down to the
     // guard row while the host reduces the AED windows below it on a separate stream; when the
     // chain of AEDs ends, the sweep continues through the rest of the block (phase B).
-    static bool const lookahead = getenv("SN_SCHUR_NOLOOKAHEAD") == nullptr;
+    bool const lookahead = !tuning().schur_nolookahead;
     std::vector<double> stale_r, stale_i;
     d.ts = s;
     d.nq = (q_rows >= 0) ? q_rows : n;
@@ -1325,7 +1328,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
-    if (getenv("SN_SCHUR_PROFILE"))
+    if (tuning().schur_profile)
         fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d; n %d sweeps %d aeds %d chain passes %ld\n",
             d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves,
             n, d.st.sweeps, d.st.aeds, d.chain_passes);
@@ -1335,6 +1338,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 
 } // namespace sn
 
+#ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- measurement hook (NOT part of the public C-ABI; scratch/chase_bench.py): average duration
 // of one schur_chase_kernel launch with `chains` full windows on a random Hessenberg matrix
 extern "C" __attribute__((visibility("default")))
@@ -1425,3 +1429,4 @@ double sn_internal_qupdate_bench(int nq, int chains, int reps, int rbm)
     SN_HIP_CHECK(hipFree(Q)); SN_HIP_CHECK(hipFree(U));
     return total / reps * 1e3;
 }
+#endif  // SN_TEST_HOOKS

@@ -18,6 +18,7 @@
 #include "schur_host.h"
 #include "dgemm_tile.h"
 #include "schur_common.h"
+#include "tuning.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -601,7 +602,7 @@ struct GepDriver {
                 ws.slot_flush[ev] = -1;
             }
             // see schur.hip (and tests/test_schur_pipeline.py) for the two wait rules
-            static bool const serial = getenv("SN_GEP_SERIAL") != nullptr;     // debugging aid
+            bool const serial = tuning().gep_serial;     // debugging aid
             if (issued > 0 && (serial || last_t != t - 1)) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
             hipLaunchKernelGGL(gep_chase_kernel, dim3(ntasks), dim3(GEP_CHASE_THREADS), GEP_CHASE_LDS_BYTES, s,
                 step, A, ldA, B, ldB, Ubuf, ws.dShiftR, ws.dShiftI);
@@ -679,7 +680,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     // multiplicity of 4 cuts the time from 8.0 s to 6.1 s but the extra chain passes raise the
     // residual from 460 u to 690 u (error ~ sqrt(number of 64-column window multiplications)),
     // above the reference harness' 500 u warning line; SN_GEP_REUSE=k selects it.
-    static int const reuse = getenv("SN_GEP_REUSE") ? std::max(1, std::min(8, atoi(getenv("SN_GEP_REUSE")))) : 1;
+    int const reuse = tuning().gep_reuse;
     ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
     GepDriver d{s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, ws, SchurStats{}};
     // the update kernel identifies "no Q" by a null pointer but still needs distinct slots
@@ -818,7 +819,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
-    if (getenv("SN_SCHUR_PROFILE"))
+    if (tuning().schur_profile)
         fprintf(stderr, "[qz] total %.3f s: aed_host %.3f, wait %.3f, push_inf %.3f s for %d infinite eigenvalues (%d windows); n %d sweeps %d aeds %d\n",
             d.st.total_ms * 1e-3, d.st.aed_host_s, d.st.wait_s, d.prof_inf_s, d.st.inf_deflated, d.prof_inf_windows,
             n, d.st.sweeps, d.st.aeds);

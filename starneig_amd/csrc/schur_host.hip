@@ -7,6 +7,7 @@
 // path needs (windows of a few hundred rows).  Everything works on HOST copies of small
 // diagonal windows; the bulk of the flops (off-diagonal updates) stays on the GPU.
 #include "schur_host.h"
+#include "tuning.h"
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -780,7 +781,7 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     double thres, double *spike, double *sr, double *si)
 {
     AedResult res{0, 0, 0};
-    static const bool prof = getenv("SN_AED_PROFILE") != nullptr;
+    bool const prof = tuning().aed_profile;
     static double t_schur = 0, t_reorder = 0, t_hess = 0; static int calls = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
@@ -871,6 +872,7 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
 
 }} // namespace sn::host
 
+#ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
 __attribute__((visibility("default")))
@@ -900,3 +902,4 @@ int sn_internal_aed_window(int nw, double *T, int ldt, double *Z, int ldz, doubl
     return 0;
 }
 }
+#endif  // SN_TEST_HOOKS

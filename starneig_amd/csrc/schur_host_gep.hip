@@ -695,6 +695,7 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
 
 }} // namespace sn::host
 
+#ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
 __attribute__((visibility("default")))
@@ -726,3 +727,4 @@ int sn_internal_gep_aed_window(int nw, double *A, int lda, double *B, int ldb, d
     return 0;
 }
 }
+#endif  // SN_TEST_HOOKS

@@ -1,0 +1,31 @@
+// Developer switches of the MI355X path, read from the environment ONCE (first use) and only when
+// STARNEIG_AMD_TUNING=1 is set; otherwise every field keeps its default.  The hot paths read plain
+// struct members, never the environment.  (scratch/README.md lists what each switch is for.)
+#pragma once
+
+namespace sn {
+
+struct Tuning {
+    // Hessenberg
+    int hess_wgs = 1024;            // SN_HESS_WGS: streaming workgroups of one gemv launch
+    int hess_max_split = 32;        // SN_HESS_MAXSPLIT
+    int hess_max_panels = 1 << 30;  // SN_HESS_MAX_PANELS: stop after k panels (PMC runs); the result is then partial
+    long hess_cache_mb = 256;       // SN_HESS_CACHE_MB: trailing matrices below this size are read with temporal loads
+    bool hess_noside = false;       // SN_HESS_NOSIDE: delayed updates on the critical stream
+    // Schur
+    bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
+    int schur_lazy_batch = 32;      // SN_SCHUR_LAZY_BATCH
+    bool schur_helpers = false;     // SN_SCHUR_HELPERS: helper threads of the host window kernels
+    int schur_reuse = 0;            // SN_SCHUR_REUSE: fixed shift multiplicity (0 = adaptive)
+    bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
+    bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
+    bool aed_profile = false;       // SN_AED_PROFILE
+    int schur_aggregate = -1;       // SN_SCHUR_AGG: -1 default, 0 off: aggregated lazy updates (tiles of window factors)
+    // QZ
+    bool gep_serial = false;        // SN_GEP_SERIAL
+    int gep_reuse = 1;              // SN_GEP_REUSE
+};
+
+Tuning const &tuning();
+
+} // namespace sn

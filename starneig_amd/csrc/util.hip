@@ -1,9 +1,39 @@
 // Small device helpers: copies, fills, the reference test driver's LCG inputs,
 // and the Frobenius-norm pieces of the acceptance checks.
 #include "common.h"
+#include "tuning.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace sn {
+
+Tuning const &tuning()
+{
+    static Tuning const t = [] {
+        Tuning t;
+        char const *on = getenv("STARNEIG_AMD_TUNING");
+        if (!on || atoi(on) == 0) return t;
+        auto geti = [](char const *k, int d) { char const *v = getenv(k); return v ? atoi(v) : d; };
+        auto getb = [](char const *k) { return getenv(k) != nullptr; };
+        t.hess_wgs = geti("SN_HESS_WGS", t.hess_wgs);
+        t.hess_max_split = geti("SN_HESS_MAXSPLIT", t.hess_max_split);
+        t.hess_max_panels = geti("SN_HESS_MAX_PANELS", t.hess_max_panels);
+        t.hess_cache_mb = geti("SN_HESS_CACHE_MB", (int)t.hess_cache_mb);
+        t.hess_noside = getb("SN_HESS_NOSIDE");
+        t.schur_nolazyrows = getb("SN_SCHUR_NOLAZYROWS");
+        t.schur_lazy_batch = geti("SN_SCHUR_LAZY_BATCH", t.schur_lazy_batch);
+        t.schur_helpers = getb("SN_SCHUR_HELPERS");
+        t.schur_reuse = std::max(0, std::min(8, geti("SN_SCHUR_REUSE", 0)));
+        t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
+        t.schur_profile = getb("SN_SCHUR_PROFILE");
+        t.aed_profile = getb("SN_AED_PROFILE");
+        t.schur_aggregate = geti("SN_SCHUR_AGG", t.schur_aggregate);
+        t.gep_serial = getb("SN_GEP_SERIAL");
+        t.gep_reuse = std::max(1, std::min(8, geti("SN_GEP_REUSE", 1)));
+        return t;
+    }();
+    return t;
+}
 
 __global__ void copy_matrix_kernel(int m, int n, double const *__restrict__ A, int lda,
     double *__restrict__ B, int ldb)

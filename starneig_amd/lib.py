@@ -128,6 +128,19 @@ SIGNATURES = {
 }
 
 _lib = None
+_test_lib = None
+TEST_LIB_PATH = os.path.join(_HERE, "libstarneig_amd_test.so")
+
+
+def load_test_hooks():
+    """The test-support build (product objects + the sn_internal_* hooks that tests/ and scratch/
+    call; csrc/Makefile).  The product library exports none of them."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError(f"{TEST_LIB_PATH} is missing: build it with `python -m starneig_amd.build`")
+        _test_lib = C.CDLL(TEST_LIB_PATH, mode=C.RTLD_LOCAL)
+    return _test_lib
 
 
 def load():

@@ -32,6 +32,20 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(S.lib.SIGNATURES)
 
 
+def test_product_library_exports_only_the_declared_interface():
+    """No measurement / test hooks in the product library: every dynamic symbol it defines is a
+    `starneig_*` entry point (the hooks live in libstarneig_amd_test.so, csrc/Makefile)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", S.lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.split()[1:2] and ln.split()[1] in "TDBW"]
+    # (compiler / HIP runtime bookkeeping symbols carry a leading underscore)
+    foreign = [n for n in names if not n.startswith("starneig_") and not n.startswith("_")]
+    assert not foreign, foreign
+    assert not [n for n in names if "sn_internal" in n]
+    hooks = subprocess.run(["nm", "-D", "--defined-only", S.lib.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "sn_internal_aed_window" in hooks
+
+
 def test_hessenberg_argument_checks():
     """hessenberg/interface.c:175-179 and :144-150 (checks precede the init check)."""
     n, ld = 5, 8

@@ -171,3 +171,21 @@ def test_random_selections_many_windows_per_round(node, seed):
     r2 = np.zeros(n); i2 = np.zeros(n)
     assert node.SEP_SM_ReorderSchur(n, sel, S, S.shape[0], Q, Q.shape[0], r2, i2) == 0
     check_reordered(A0, S, Q, r2, i2, eigs, sel, n)
+
+
+def test_values_per_chain_one_with_selected_complex_pairs(node):
+    """conf->values_per_chain = 1 and selected 2x2 blocks: the first selected block of a window is
+    admitted whatever its size (a round loop that could not place a 2x2 block never ended)"""
+    n = 300
+    A0, S, Q, real, imag = schur_of_lcg(node, n)
+    assert (imag > 0).any()
+    sel = np.zeros(n, dtype=np.int32)
+    pairs = [i for i in range(n - 1) if imag[i] > 0.0]
+    for i in pairs[len(pairs) // 2:]:
+        sel[i] = sel[i + 1] = 1
+    sel[n - 1] = 1 if imag[n - 1] == 0.0 else sel[n - 1]
+    eigs = [real[i] + 1j * imag[i] for i in range(n) if sel[i]]
+    conf = node.reorder_init_conf(); conf.window_size = 16; conf.values_per_chain = 1
+    r2 = np.zeros(n); i2 = np.zeros(n)
+    assert node.SEP_SM_ReorderSchur(n, sel, S, S.shape[0], Q, Q.shape[0], r2, i2, conf=conf) == 0
+    check_reordered(A0, S, Q, r2, i2, eigs, sel, n)

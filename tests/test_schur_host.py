@@ -18,7 +18,7 @@ def P(a):
 
 
 def lib():
-    L = S.lib.load()
+    L = S.lib.load_test_hooks()
     L.sn_internal_small_schur.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, dp]
     L.sn_internal_move_block_up.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int]
     L.sn_internal_extract_shifts.argtypes = [C.c_int, dp, C.c_int, dp, dp]
@@ -126,7 +126,7 @@ def test_reorder_window_moves_selected_blocks_to_the_top(n, seed):
     """host::reorder_window (the window kernel of starneig_SEP_SM_ReorderSchur; reference
     reorder/cpu.c, LAPACK dtrsen semantics): selected blocks at the top in their original order,
     similarity and orthogonality preserved, marks follow the rows, against scipy's sorted Schur."""
-    L = S.lib.load()
+    L = S.lib.load_test_hooks()
     ip = C.POINTER(C.c_int)
     L.sn_internal_reorder_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, ip, ip]
     H0 = hess_input(n, seed=seed)
@@ -193,7 +193,7 @@ def test_reorder_window_rejected_swap_keeps_a_valid_decomposition():
     the Sylvester equation of the exchange is (nearly) singular, dlaexc's acceptance test rejects
     the swap (reorder/cpu.c -> STARNEIG_PARTIAL_REORDERING).  The kernel must then report `failed`,
     leave a valid similarity behind and keep the marks on the rows where the blocks now are."""
-    L = S.lib.load()
+    L = S.lib.load_test_hooks()
     ip = C.POINTER(C.c_int)
     L.sn_internal_reorder_window.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, ip, ip]
     n = 8

@@ -19,7 +19,7 @@ def P(a):
 
 
 def lib():
-    L = S.lib.load()
+    L = S.lib.load_test_hooks()
     L.sn_internal_gep_small_schur.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [dp, dp, dp]
     L.sn_internal_gep_ht_reduce.argtypes = [C.c_int, C.c_int, C.c_int] + [dp, C.c_int] * 4
     L.sn_internal_gep_aed_window.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [C.c_double, C.c_double, dp, dp, dp,
