@@ -51,6 +51,56 @@ def qz_flops(n):
     return 66.0 * n ** 3            # Golub & Van Loan QZ with Q and Z
 
 
+def qz_pencil(S, n, kind):
+    """Device-resident Hessenberg-triangular pencil.  kind "lcg": the reference test driver's
+    random pencil (test/common/init.c:122-175, seed 2019; BASELINE config 5 -- its triangular
+    factor is very ill-conditioned and the reduction is almost entirely AED).  kind "wellcond":
+    the same draws with R <- triu(R,1)/sqrt(n) + diag(1 + |r_ii|) (oracle.random_pencil_wellcond):
+    finite, well separated eigenvalues, so the QZ *sweeps* carry the reduction."""
+    import torch
+    tH0, tR0 = S.device_matrix(n), S.device_matrix(n)
+    assert S.lcg_pencil_device(tH0, tR0, n, seed=2019) == 0
+    if kind == "wellcond":
+        R = tR0[:, :n]                       # R[c, r] = R(r, c): the upper triangle is torch's lower one
+        d = torch.diagonal(R).abs() + 1.0
+        R.copy_(torch.tril(R, -1) / float(n) ** 0.5)
+        torch.diagonal(R).copy_(d)
+    return tH0, tR0
+
+
+def run_qz(S, n, kind, steps, warmup):
+    """Times `steps` generalized Schur (QZ) reductions of one device-resident pencil; returns the
+    fields of a bench line (value by the 66 n^3 convention, executed GEMM flops beside it)."""
+    import torch
+    tH0, tR0 = qz_pencil(S, n, kind)
+    tQ, tZ = S.device_matrix(n), S.device_matrix(n)
+    times, st = [], None
+    for it in range(warmup + steps):
+        tH, tR = tH0.clone(), tR0.clone()
+        S.set_matrix_device(tQ, n, n, 0.0, 1.0); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc, ar, ai, be, st = S.gep_schur_device(tH, tR, tQ, tZ, n=n)
+        torch.cuda.synchronize()
+        assert rc == 0, f"gep schur rc={rc}"
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    _, ca = S.check_pencil_device(tQ, tH, tZ, tH0, n=n)
+    _, cb = S.check_pencil_device(tQ, tR, tZ, tR0, n=n)
+    total = sum(times)
+    out = {"pencil": kind, "n": n, "steps": steps, "seconds_per_step": total / steps,
+           "value": steps * qz_flops(n) / total / 1e9, "unit": "GFLOP/s (66 n^3 convention)",
+           "executed_gemm_tflop_per_step": st["gemm_flops"] / 1e12,
+           "executed_tflops_per_s": st["gemm_flops"] / 1e12 / (total / steps),
+           "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
+           "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
+           "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
+           "qz_sweeps": st["sweeps"], "aeds": st["aeds"], "aed_host_s": st["aed_host_s"]}
+    del tH0, tR0, tQ, tZ
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_qz(args):
     """BASELINE config 5 (not the headline metric): generalized Schur (QZ) reduction of the
     reference test driver's random Hessenberg-triangular pencil, n = 12000 by default, Q = Z = I,
@@ -61,37 +111,15 @@ def bench_qz(args):
     import starneig_amd as S
     S.node_init(1, 1, S.NO_MESSAGES)
     n = args.n if args.n != 20000 else 12000
-    tH0, tR0 = S.device_matrix(n), S.device_matrix(n)
-    assert S.lcg_pencil_device(tH0, tR0, n, seed=2019) == 0
-    tQ, tZ = S.device_matrix(n), S.device_matrix(n)
-    times, st = [], None
-    for it in range(args.warmup + args.steps):
-        tH, tR = tH0.clone(), tR0.clone()
-        S.set_matrix_device(tQ, n, n, 0.0, 1.0); S.set_matrix_device(tZ, n, n, 0.0, 1.0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc, ar, ai, be, st = S.gep_schur_device(tH, tR, tQ, tZ, n=n)
-        torch.cuda.synchronize()
-        assert rc == 0, f"gep schur rc={rc}"
-        if it >= args.warmup:
-            times.append(time.perf_counter() - t0)
-    _, ca = S.check_pencil_device(tQ, tH, tZ, tH0, n=n)
-    _, cb = S.check_pencil_device(tQ, tR, tZ, tR0, n=n)
-    total = sum(times)
+    r = run_qz(S, n, args.pencil, args.steps, args.warmup)
     print(json.dumps({
         "metric": "GFLOP/s generalized Schur (QZ), n=12000 Hessenberg-triangular pencil, 1 MI355X",
-        "value": args.steps * qz_flops(n) / total / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": total / args.steps * 1e3,
+        "value": r["value"], "unit": "GFLOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["seconds_per_step"] * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"QZ, n={n}, Q and Z accumulated, LCG pencil seed 2019 (BASELINE config 5); "
-                               f"value = 66 n^3 flop / time",
-                   "n": n, "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
-                   "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
-                   "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
-                   "qz_sweeps": st["sweeps"], "aeds": st["aeds"],
-                   "executed_gemm_tflop_per_step": st["gemm_flops"] / 1e12,
-                   "aed_host_s": st["aed_host_s"]},
+        "config": dict(r, workload=f"QZ, n={n}, Q and Z accumulated, {args.pencil} pencil seed 2019 "
+                                   f"(BASELINE config 5); value = 66 n^3 flop / time"),
     }), flush=True)
     S.node_finalize()
 
@@ -189,7 +217,9 @@ def cpu_baseline(n_lapack, n_port):
         loops; OpenMP Hessenberg, scalar double-shift Schur) at a smaller size.
     Both are reported baselines, not targets."""
     import numpy as np
-    out = {"unit": "GFLOP/s", "kind": "port"}
+    # kind: "lapack" -- neither a build of the reference (impossible here) nor the oracle port; the
+    # port's own number is the `oracle_port` entry
+    out = {"unit": "GFLOP/s", "kind": "lapack"}
     cores = os.cpu_count() or 1
     if n_lapack > 0:
         import scipy.linalg as sl
@@ -333,7 +363,8 @@ def main():
                     help="untimed steps (the first call allocates the cached workspaces and creates ~10^4 events)")
     ap.add_argument("--size", "--n", dest="n", type=int, default=20000)
     ap.add_argument("--cpu-n", type=int, default=4000,
-                    help="size of the LAPACK CPU-baseline sample (0 = skip; n=4000 is ~30 s on the GPU box's host)")
+                    help="size of the LAPACK CPU-baseline sample (0 = skip; n=4000 is ~30 s on the GPU box's host, "
+                         "n=8000 ~4 min)")
     ap.add_argument("--cpu-port-n", type=int, default=1000,
                     help="size of the oracle-port CPU sample (0 = skip)")
     ap.add_argument("--host-api", type=int, default=1,
@@ -345,6 +376,11 @@ def main():
                          "ht = Hessenberg-triangular reduction (the step before config 5)")
     ap.add_argument("--cpu-ht-n", type=int, default=1500,
                     help="size of the LAPACK sample of the ht workload (0 = skip)")
+    ap.add_argument("--pencil", choices=["lcg", "wellcond"], default="lcg",
+                    help="qz workload: the test driver's pencil (config 5) or its well-conditioned variant")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="1: append the QZ legs (config 5 and the well-conditioned pencil, n=12000, one timed "
+                         "step each) to the default line as `secondary`, N=1 only")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
@@ -473,6 +509,9 @@ def main():
                 "schur_sweeps": stats[-1]["schur"]["sweeps"], "schur_aeds": stats[-1]["schur"]["aeds"],
                 "executed_gemm_tflop_per_step":
                     (stats[-1]["gemm_flops"] + stats[-1]["schur"]["gemm_flops"]) / 1e12,
+                # the executed GEMM work over the step time, beside the convention-based `value`
+                "executed_tflops_per_s":
+                    sum(s_["gemm_flops"] + s_["schur"]["gemm_flops"] for s_ in stats) / 1e12 / total,
             },
             "roofline": {
                 "kernel": "hess_gemv_kernel (panel y = A v, rows H2 of SURVEY 8a)",
@@ -508,6 +547,10 @@ def main():
             out["config"]["host_api_s"] = host_api_call(S, n)
         if world == 1 and (args.cpu_n > 0 or args.cpu_port_n > 0):
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.cpu_port_n)
+        if world == 1 and args.secondary and not sharded:
+            # driver-timed secondary workloads (not part of `value`): BASELINE config 5 and the same
+            # size on a well-conditioned pencil, where the QZ sweeps -- not the host AED -- do the work
+            out["secondary"] = [run_qz(S, 12000, "lcg", 1, 1), run_qz(S, 12000, "wellcond", 1, 1)]
 
     if sharded:
         from starneig_amd import distributed as _D

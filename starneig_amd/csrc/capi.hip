@@ -22,6 +22,9 @@ int reorder_schur_device(hipStream_t caller, int n, int *selected, double *dS, i
     double *dQ, int ldQ, double *real, double *imag, int window_size, int values_per_chain,
     double *stats, int host_threads);
 void reorder_release_workspace();
+void upload_host_matrix(double *dev, int ldd, double const *host, int ldh, int rows, int cols, int threads);
+void download_host_matrix(double *host, int ldh, double const *dev, int ldd, int rows, int cols, int threads);
+void staging_release();
 }
 
 namespace {
@@ -48,6 +51,17 @@ void require_device()
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && g_node.messages)
         fprintf(stderr, "[starneig-amd] warning: device is %s, kernels are built for gfx950\n",
             prop.gcnArchName);
+}
+
+// caller's (pageable) array <-> HBM, complete on return (staging.hip)
+void to_device(double *dev, int ldd, double const *host, int ldh, int n)
+{
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr));        // the buffer was cleared on the NULL stream
+    sn::upload_host_matrix(dev, ldd, host, ldh, n, n, g_node.cores);
+}
+void to_host(double *host, int ldh, double const *dev, int ldd, int n)
+{
+    sn::download_host_matrix(host, ldh, dev, ldd, n, n, g_node.cores);
 }
 
 int default_panel_width(int n)          // hessenberg/interface.c:74-78
@@ -116,6 +130,7 @@ SN_API void starneig_node_finalize(void)
     sn::gep_schur_release_workspace();
     sn::reorder_release_workspace();
     sn::hessenberg_triangular_release_workspace();
+    sn::staging_release();
     g_node.initialized = false;
 }
 
@@ -180,18 +195,14 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     }
     SN_HIP_CHECK(hipMemset(dA, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
-    SN_HIP_CHECK(hipMemcpy2D(dA, (size_t)ld * 8, A, (size_t)ldA * 8, (size_t)n * 8, n,
-        hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n,
-        hipMemcpyHostToDevice));
+    to_device(dA, ld, A, ldA, n);
+    to_device(dQ, ld, Q, ldQ, n);
 
     int rc = sn::hessenberg_device(nullptr, n, begin, end, panel_width, dA, ld, dQ, ld, nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
 
-    SN_HIP_CHECK(hipMemcpy2D(A, (size_t)ldA * 8, dA, (size_t)ld * 8, (size_t)n * 8, n,
-        hipMemcpyDeviceToHost));
-    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n,
-        hipMemcpyDeviceToHost));
+    to_host(A, ldA, dA, ld, n);
+    to_host(Q, ldQ, dQ, ld, n);
     if (g_node.pinning) { (void)hipHostUnregister(A); (void)hipHostUnregister(Q); }
     SN_HIP_CHECK(hipFree(dA));
     SN_HIP_CHECK(hipFree(dQ));
@@ -292,19 +303,15 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
     SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
     SN_HIP_CHECK(hipMemset(dH, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
-    SN_HIP_CHECK(hipMemcpy2D(dH, (size_t)ld * 8, H, (size_t)ldH * 8, (size_t)n * 8, n,
-        hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n,
-        hipMemcpyHostToDevice));
+    to_device(dH, ld, H, ldH, n);
+    to_device(dQ, ld, Q, ldQ, n);
     std::vector<double> wr, wi;
     double *pr = real, *pi = imag;
     if (real == NULL || imag == NULL) { pr = pi = nullptr; }    // schur/core.c:2501
     rc = sn::schur_device(nullptr, n, dH, ld, dQ, ld, pr, pi, prm, nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
-    SN_HIP_CHECK(hipMemcpy2D(H, (size_t)ldH * 8, dH, (size_t)ld * 8, (size_t)n * 8, n,
-        hipMemcpyDeviceToHost));
-    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n,
-        hipMemcpyDeviceToHost));
+    to_host(H, ldH, dH, ld, n);
+    to_host(Q, ldQ, dQ, ld, n);
     SN_HIP_CHECK(hipFree(dH));
     SN_HIP_CHECK(hipFree(dQ));
     return rc;
@@ -417,13 +424,13 @@ SN_API starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
     SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
     SN_HIP_CHECK(hipMemset(dS, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
-    SN_HIP_CHECK(hipMemcpy2D(dS, (size_t)ld * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipMemcpy2D(dQ, (size_t)ld * 8, Q, (size_t)ldQ * 8, (size_t)n * 8, n, hipMemcpyHostToDevice));
+    to_device(dS, ld, S, ldS, n);
+    to_device(dQ, ld, Q, ldQ, n);
     if (real == NULL || imag == NULL) real = imag = nullptr;
     rc = sn::reorder_schur_device(nullptr, n, selected, dS, ld, dQ, ld, real, imag, window, vpc, nullptr, g_node.cores);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
-    SN_HIP_CHECK(hipMemcpy2D(S, (size_t)ldS * 8, dS, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
-    SN_HIP_CHECK(hipMemcpy2D(Q, (size_t)ldQ * 8, dQ, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+    to_host(S, ldS, dS, ld, n);
+    to_host(Q, ldQ, dQ, ld, n);
     SN_HIP_CHECK(hipFree(dS));
     SN_HIP_CHECK(hipFree(dQ));
     return rc;
@@ -514,16 +521,14 @@ SN_API starneig_error_t starneig_GEP_SM_Schur_expert(
     for (int i = 0; i < 4; i++) {
         SN_HIP_CHECK(hipMalloc((void **)&dev[i], bytes));
         SN_HIP_CHECK(hipMemset(dev[i], 0, bytes));
-        SN_HIP_CHECK(hipMemcpy2D(dev[i], (size_t)ld * 8, host[i], (size_t)lds[i] * 8, (size_t)n * 8, n,
-            hipMemcpyHostToDevice));
+        to_device(dev[i], ld, host[i], lds[i], n);
     }
     if (real == NULL || imag == NULL || beta == NULL) real = imag = beta = nullptr;
     rc = sn::gep_schur_device(nullptr, n, dev[0], ld, dev[1], ld, dev[2], ld, dev[3], ld,
         real, imag, beta, prm, nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
     for (int i = 0; i < 4; i++) {
-        SN_HIP_CHECK(hipMemcpy2D(host[i], (size_t)lds[i] * 8, dev[i], (size_t)ld * 8, (size_t)n * 8, n,
-            hipMemcpyDeviceToHost));
+        to_host(host[i], lds[i], dev[i], ld, n);
         SN_HIP_CHECK(hipFree(dev[i]));
     }
     return rc;
@@ -569,14 +574,12 @@ SN_API starneig_error_t starneig_GEP_SM_HessenbergTriangular(
     for (int i = 0; i < 4; i++) {
         SN_HIP_CHECK(hipMalloc((void **)&dev[i], bytes));
         SN_HIP_CHECK(hipMemset(dev[i], 0, bytes));
-        SN_HIP_CHECK(hipMemcpy2D(dev[i], (size_t)ld * 8, host[i], (size_t)lds[i] * 8, (size_t)n * 8, n,
-            hipMemcpyHostToDevice));
+        to_device(dev[i], ld, host[i], lds[i], n);
     }
     int const rc = sn::hessenberg_triangular_device(nullptr, n, dev[0], ld, dev[1], ld, dev[2], ld, dev[3], ld, nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(nullptr));
     for (int i = 0; i < 4; i++) {
-        SN_HIP_CHECK(hipMemcpy2D(host[i], (size_t)lds[i] * 8, dev[i], (size_t)ld * 8, (size_t)n * 8, n,
-            hipMemcpyDeviceToHost));
+        to_host(host[i], lds[i], dev[i], ld, n);
         SN_HIP_CHECK(hipFree(dev[i]));
     }
     return rc;
@@ -861,12 +864,12 @@ SN_API starneig_error_t starneig_amd_check_device(
     SN_HIP_CHECK(hipMalloc((void **)&acc, 4 * sizeof(double)));
     SN_HIP_CHECK(hipMemsetAsync(acc, 0, 4 * sizeof(double), s));
     // W1 = Q H ; W2 = W1 Q^T ; ||W2 - A||_F / ||A||_F       (checks.c:180-194)
-    sn::dgemm(s, 'N', 'N', n, n, n, 1.0, dQ, ldQ, dH, ldH, 0.0, dWork1, n);
-    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dWork1, n, dQ, ldQ, 0.0, dWork2, n);
+    sn::dgemm_accurate(s, 'N', 'N', n, n, n, dQ, ldQ, dH, ldH, dWork1, n);
+    sn::dgemm_accurate(s, 'N', 'T', n, n, n, dWork1, n, dQ, ldQ, dWork2, n);
     sn::sumsq_diff(s, n, n, dWork2, n, dA0, ldA0, 0.0, acc + 0);
     sn::sumsq_diff(s, n, n, dA0, ldA0, nullptr, 0, 0.0, acc + 1);
     // ||Q Q^T - I||_F / sqrt(n)                              (checks.c:196-208)
-    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dQ, ldQ, dQ, ldQ, 0.0, dWork1, n);
+    sn::dgemm_accurate(s, 'N', 'T', n, n, n, dQ, ldQ, dQ, ldQ, dWork1, n);
     sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 2);
     sn::count_below(s, n, dH, ldH, acc + 3);
     double h[4];
@@ -890,13 +893,13 @@ SN_API starneig_error_t starneig_amd_check_pencil_device(
     double *acc = nullptr;
     SN_HIP_CHECK(hipMalloc((void **)&acc, 5 * sizeof(double)));
     SN_HIP_CHECK(hipMemsetAsync(acc, 0, 5 * sizeof(double), s));
-    sn::dgemm(s, 'N', 'N', n, n, n, 1.0, dQ, ldQ, dS, ldS, 0.0, dWork1, n);
-    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dWork1, n, dZ, ldZ, 0.0, dWork2, n);
+    sn::dgemm_accurate(s, 'N', 'N', n, n, n, dQ, ldQ, dS, ldS, dWork1, n);
+    sn::dgemm_accurate(s, 'N', 'T', n, n, n, dWork1, n, dZ, ldZ, dWork2, n);
     sn::sumsq_diff(s, n, n, dWork2, n, dA0, ldA0, 0.0, acc + 0);
     sn::sumsq_diff(s, n, n, dA0, ldA0, nullptr, 0, 0.0, acc + 1);
-    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dQ, ldQ, dQ, ldQ, 0.0, dWork1, n);
+    sn::dgemm_accurate(s, 'N', 'T', n, n, n, dQ, ldQ, dQ, ldQ, dWork1, n);
     sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 2);
-    sn::dgemm(s, 'N', 'T', n, n, n, 1.0, dZ, ldZ, dZ, ldZ, 0.0, dWork1, n);
+    sn::dgemm_accurate(s, 'N', 'T', n, n, n, dZ, ldZ, dZ, ldZ, dWork1, n);
     sn::sumsq_diff(s, n, n, dWork1, n, nullptr, 0, 1.0, acc + 3);
     sn::count_below(s, n, dS, ldS, acc + 4);
     double h[5];

@@ -28,6 +28,9 @@ void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
     double alpha, double const *A, int lda, double const *B, int ldb,
     double beta, double *C, int ldc);
 
+void dgemm_accurate(hipStream_t s, char transA, char transB, int m, int n, int k,
+    double const *A, int lda, double const *B, int ldb, double *C, int ldc);
+
 struct GemmDesc {               // one problem of a batched launch (device pointers)
     double const *A; double const *B; double *C;
     int m, n, k, lda, ldb, ldc;

@@ -21,15 +21,16 @@
 // bank-conflict free.
 #include "common.h"
 #include "dgemm_tile.h"
+#include "tuning.h"
 #include <algorithm>
 
 namespace sn {
 
-template <int BM, int BN, int KT, bool TA, bool TB>
+template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH>
 __global__ __launch_bounds__(256, 2)
 void dgemm_kernel(int m, int n, int k, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double beta, double *__restrict__ C, int ldc, int tiles_m)
+    double beta, double *__restrict__ C, int ldc, int tiles_m, int separate_sum)
 {
     // Tile order (speed only): blocks are dealt round-robin over the 8 XCDs, so give every
     // XCD a contiguous range of tile ids (its private L2 then sees neighbouring tiles), and
@@ -44,7 +45,7 @@ void dgemm_kernel(int m, int n, int k, double alpha,
     int const group = pid / in_group, first_m = group * GROUP_M;
     int const gsize = min(tiles_m - first_m, GROUP_M);
     int const bm = first_m + (pid % in_group) % gsize, bn = (pid % in_group) / gsize;
-    gemm_tile<BM, BN, KT, TA, TB>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn);
+    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn, false, separate_sum != 0);
 }
 
 // Split-K form for outputs with few tiles and a long inner dimension (the inner-product shaped
@@ -52,7 +53,7 @@ void dgemm_kernel(int m, int n, int k, double alpha,
 // width, k = trailing rows): blockIdx.y selects a slice of k, the slices are summed into C
 // (zeroed by the caller) with fp64 atomics.  Besides filling the chip this shortens the
 // sequential accumulation chains from k to k / slices terms.
-template <int BM, int BN, int KT, bool TA, bool TB>
+template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH>
 __global__ __launch_bounds__(256, 2)
 void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
@@ -62,7 +63,7 @@ void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     if (kl <= 0) return;
     double const *Ak = TA ? A + k0 : A + (size_t)k0 * lda;
     double const *Bk = TB ? B + (size_t)k0 * ldb : B + k0;
-    gemm_tile<BM, BN, KT, TA, TB>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc,
+    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc,
         blockIdx.x % tiles_m, blockIdx.x / tiles_m, true);
 }
 
@@ -113,7 +114,10 @@ static void launch(hipStream_t s, int m, int n, int k, double alpha,
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
     static bool attr_set = false;
-    auto kern = dgemm_kernel<BM, BN, KT, TA, TB>;
+    // two-level summation (chunks of 256 terms) wherever the second accumulator set fits the
+    // register budget of two workgroups per CU: every tile shape but 128 x 128
+    constexpr int FLUSH = (BM * BN <= 128 * 64) ? 256 / KT : 0;
+    auto kern = dgemm_kernel<BM, BN, KT, TA, TB, FLUSH>;
     if (!attr_set) {
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
@@ -121,7 +125,7 @@ static void launch(hipStream_t s, int m, int n, int k, double alpha,
     }
     int tiles_m = divceil(m, BM), tiles_n = divceil(n, BN);
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s,
-        m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tiles_m);
+        m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tiles_m, tuning().gemm_separate_sum ? 1 : 0);
 }
 
 template <int BM, int BN, bool TA, bool TB>
@@ -130,7 +134,7 @@ static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double
 {
     using Cfg = GemmCfg<BM, BN, 16, TA, TB>;
     static bool attr_set = false;
-    auto kern = dgemm_splitk_kernel<BM, BN, 16, TA, TB>;
+    auto kern = dgemm_splitk_kernel<BM, BN, 16, TA, TB, 256 / 16>;
     if (!attr_set) {
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
@@ -156,6 +160,11 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
         // Target: ~6 work items per workgroup slot (256 CUs x 2), slices of >= 512.
         long const t128 = (long)divceil(m, 128) * divceil(n, 64);
         long const t64 = (long)divceil(m, 64) * divceil(n, 64);
+        int const kchunk = tuning().gemm_kchunk;
+        if (kchunk > 0 && t64 > 64) {
+            launch_splitk<128, 64, TA, TB>(s, m, n, k, divceil(k, kchunk), alpha, A, lda, B, ldb, C, ldc);
+            return;
+        }
         if (t64 <= 64) {
             int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, 1024 / t64));
             launch_splitk<64, 64, TA, TB>(s, m, n, k, slices, alpha, A, lda, B, ldb, C, ldc);
@@ -199,6 +208,20 @@ void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int l
     if (w <= 0 || nrows <= 0) return;
     if (w > 128) { fprintf(stderr, "[starneig-amd] dgemm_right_inplace: w > 128\n"); abort(); }
     launch<128, 128, 16, false, false>(s, nrows, w, w, 1.0, X, ldx, U, ldu, 0.0, X, ldx);
+}
+
+// C = op(A) op(B) with 128 x 64 tiles and two-level summation whatever the shape: the acceptance
+// checks (||Q Q^T - I||, ||Q H Q^T - A||) must not add rounding noise of their own -- a single
+// chain over k = n = 20000 costs ~10 u on the diagonal of Q Q^T
+void dgemm_accurate(hipStream_t s, char transA, char transB, int m, int n, int k,
+    double const *A, int lda, double const *B, int ldb, double *C, int ldc)
+{
+    if (m <= 0 || n <= 0) return;
+    bool ta = (transA == 'T' || transA == 't'), tb = (transB == 'T' || transB == 't');
+    if (ta && tb)        launch<128, 64, 16, true, true>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
+    else if (ta && !tb)  launch<128, 64, 16, true, false>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
+    else if (!ta && tb)  launch<128, 64, 16, false, true>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
+    else                 launch<128, 64, 16, false, false>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
 }
 
 void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,

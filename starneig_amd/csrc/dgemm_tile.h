@@ -26,11 +26,16 @@ struct GemmCfg {
     static constexpr int LDS_BYTES = 2 * (R_ELEMS + C_ELEMS) * 8;
 };
 
-template <int BM, int BN, int KT, bool TA, bool TB>
+// FLUSH > 0: two-level summation -- the accumulators are folded into a second set every FLUSH
+// k-tiles (FLUSH * KT terms) and restart from zero, so a sum over a long k is a short chain of
+// chunk sums instead of one chain of k / 4 roundings at the magnitude of the result (the rounding
+// error of a length-k chain grows like sqrt(k); measured on the accumulation of Q: DESIGN.md).
+template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH = 0>
 __device__ __forceinline__
 void gemm_tile(int m, int n, int k, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double beta, double *__restrict__ C, int ldc, int bm, int bn, bool atomic = false)
+    double beta, double *__restrict__ C, int ldc, int bm, int bn, bool atomic = false,
+    bool separate_sum = false)
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -47,7 +52,7 @@ void gemm_tile(int m, int n, int k, double alpha,
     // accumulators START as the old C tile and the column operand carries the sign, so the tile
     // is read while the first operand tiles are in flight and the epilogue is stores only --
     // instead of a dependent load / fma / store tail after the last MFMA.
-    bool const accinit = !atomic && beta == 1.0 && (alpha == 1.0 || alpha == -1.0);
+    bool const accinit = !atomic && !separate_sum && beta == 1.0 && (alpha == 1.0 || alpha == -1.0);
     double const opscale = accinit ? alpha : 1.0;
     // interior tiles: straight 16-byte loads, no per-element bounds tests
     bool const tile_full = (r0 + BM <= m) && (c0 + BN <= n);
@@ -128,11 +133,15 @@ void gemm_tile(int m, int n, int k, double alpha,
     };
 
     d4 acc[Cfg::TN][Cfg::TM];
+    constexpr bool TWO = FLUSH > 0;
+    d4 acc2[TWO ? Cfg::TN : 1][TWO ? Cfg::TM : 1];
     #pragma unroll
     for (int ci = 0; ci < Cfg::TN; ci++)
         #pragma unroll
-        for (int ri = 0; ri < Cfg::TM; ri++)
+        for (int ri = 0; ri < Cfg::TM; ri++) {
             acc[ci][ri] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (TWO) acc2[TWO ? ci : 0][TWO ? ri : 0] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
 
     int const l15 = lane & 15, l4 = lane >> 4;
     int const nkt = (k + KT - 1) / KT;
@@ -146,7 +155,10 @@ void gemm_tile(int m, int n, int k, double alpha,
                 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
-                    if (tile_full || (r < m && c < n)) acc[ci][ri][reg] = C[(size_t)c * ldc + r];
+                    if (tile_full || (r < m && c < n)) {
+                        if (TWO) acc2[TWO ? ci : 0][TWO ? ri : 0][reg] = C[(size_t)c * ldc + r];
+                        else acc[ci][ri][reg] = C[(size_t)c * ldc + r];
+                    }
                 }
             }
     }
@@ -178,6 +190,16 @@ void gemm_tile(int m, int n, int k, double alpha,
                 for (int ri = 0; ri < Cfg::TM; ri++)
                     acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                         fc[ci], fr[ri], acc[ci][ri], 0, 0, 0);
+        }
+
+        if (TWO && ((kt + 1) % (TWO ? FLUSH : 1) == 0 || kt + 1 == nkt)) {
+            #pragma unroll
+            for (int ci = 0; ci < Cfg::TN; ci++)
+                #pragma unroll
+                for (int ri = 0; ri < Cfg::TM; ri++) {
+                    acc2[TWO ? ci : 0][TWO ? ri : 0] += acc[ci][ri];
+                    acc[ci][ri] = (kt + 1 == nkt) ? acc2[TWO ? ci : 0][TWO ? ri : 0] : (d4){0.0, 0.0, 0.0, 0.0};
+                }
         }
 
         if (kt + 1 < nkt) store_tiles(buf ^ 1);

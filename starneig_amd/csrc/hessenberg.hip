@@ -900,3 +900,24 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
 }
 
 } // namespace sn
+
+#ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile)
+// scratch/hess_panel_probe.py: the panel factors [V | VT] and the reflector scalars of the panel
+// that was factorised last (buffer slot `buf`), copied to the host as ldp x nb column-major blocks
+extern "C" __attribute__((visibility("default")))
+int sn_internal_hess_panel_factors(int buf, int nb, double *V, double *VT, double *scal, int *ldp_out)
+{
+    using namespace sn;
+    HessWorkspace &ws = g_ws;
+    if (!ws.P || nb > ws.nbmax) return -1;
+    SN_HIP_CHECK(hipDeviceSynchronize());
+    size_t const pan = (size_t)ws.ldp * nb;
+    double *Y = ws.YVW[buf];
+    SN_HIP_CHECK(hipMemcpy(V, Y + pan, pan * 8, hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipMemcpy(VT, ws.VT[buf], pan * 8, hipMemcpyDeviceToHost));
+    SN_HIP_CHECK(hipMemcpy(scal, ws.scal, (size_t)4 * nb * 8, hipMemcpyDeviceToHost));
+    *ldp_out = ws.ldp;
+    return 0;
+}
+#endif  // SN_TEST_HOOKS
+

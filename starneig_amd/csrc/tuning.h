@@ -21,6 +21,10 @@ struct Tuning {
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
     bool aed_profile = false;       // SN_AED_PROFILE
     int schur_aggregate = -1;       // SN_SCHUR_AGG: -1 default, 0 off: aggregated lazy updates (tiles of window factors)
+    int schur_cumask = 0;           // SN_SCHUR_CUMASK: CUs kept free of the lazy update streams (0 = no mask)
+    // GEMM
+    bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)
+    int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 1;              // SN_GEP_REUSE

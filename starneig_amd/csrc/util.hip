@@ -4,6 +4,7 @@
 #include "tuning.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace sn {
 
@@ -14,7 +15,7 @@ Tuning const &tuning()
         char const *on = getenv("STARNEIG_AMD_TUNING");
         if (!on || atoi(on) == 0) return t;
         auto geti = [](char const *k, int d) { char const *v = getenv(k); return v ? atoi(v) : d; };
-        auto getb = [](char const *k) { return getenv(k) != nullptr; };
+        auto getb = [](char const *k) { char const *v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
         t.hess_wgs = geti("SN_HESS_WGS", t.hess_wgs);
         t.hess_max_split = geti("SN_HESS_MAXSPLIT", t.hess_max_split);
         t.hess_max_panels = geti("SN_HESS_MAX_PANELS", t.hess_max_panels);
@@ -28,6 +29,9 @@ Tuning const &tuning()
         t.schur_profile = getb("SN_SCHUR_PROFILE");
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_aggregate = geti("SN_SCHUR_AGG", t.schur_aggregate);
+        t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);
+        t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
+        t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
         t.gep_serial = getb("SN_GEP_SERIAL");
         t.gep_reuse = std::max(1, std::min(8, geti("SN_GEP_REUSE", 1)));
         return t;

@@ -44,8 +44,9 @@ def test_config3_hessenberg_schur_n20000(node):
     assert node.hessenberg_device(tH, tQ, n=n) == 0
     rc, chk = node.check_device(tQ, tH, tA0, n=n)
     assert rc == 0 and chk["below_subdiagonal"] == 0
-    # 4 x the reference's published Hessenberg residuals at n = 4000 (15 u / 11 u), sqrt(n) growth
-    assert chk["residual_u"] < 4 * 15 * np.sqrt(5) and chk["orthogonality_u"] < 4 * 11 * np.sqrt(5)
+    # 1.5 x the reference's published Hessenberg residuals at n = 4000 (15 u / 11 u); no allowance
+    # for the five times larger n
+    assert chk["residual_u"] < 1.5 * 15 and chk["orthogonality_u"] < 1.5 * 11
     trace = float(torch.diagonal(tA0[:, :n]).sum())
     assert abs(float(torch.diagonal(tH[:, :n]).sum()) - trace) <= 1e-9 * n
     rc, real, imag, st = node.schur_device(tH, tQ, n=n)

@@ -15,9 +15,11 @@ from test_oracle import partial_input
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
-# reference's own measured values at n=4000 (docs/_7_test_driver.md:233-247): 15 u / 11 u.
-REF_RESIDUAL_U = 15.0 * 4
-REF_ORTH_U = 11.0 * 4
+# reference's own measured values at n=4000 (docs/_7_test_driver.md:233-247): 15 u / 11 u; the
+# limit is 1.5 x those (round 3 measures 9.5 u / 8.9 u at n = 4000, 9.7 u / 9.2 u at n = 8000: the
+# GEMM updates sum every product from zero in chunks of 256 terms)
+REF_RESIDUAL_U = 15.0 * 1.5
+REF_ORTH_U = 11.0 * 1.5
 
 
 def run_host_api(S, A0, begin=0, end=None, panel_width=None):
@@ -144,11 +146,11 @@ def test_device_checks_agree_with_oracle_checks(node):
     assert chk["orthogonality_u"] == pytest.approx(O.orthogonality_u(Q), rel=0.5)
 
 
-@pytest.mark.parametrize("n", [2000, 8000])
+@pytest.mark.parametrize("n", [2000, 4000, 8000])
 def test_baseline_sizes_properties(node, n):
     """BASELINE configs 1-2 (n=2000, n=8000): size-independent acceptance checks of the
     reference (test/common/hooks.c:434-456, checks.c:180-208) on the LCG input, all on
-    the GPU; limits = the reference's own measured residuals x4 (docs/_7_test_driver.md)."""
+    the GPU; limits = the reference's own measured residuals x 1.5 (docs/_7_test_driver.md)."""
     tA0 = node.device_matrix(n)
     assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
     tA = tA0.clone()
