@@ -327,15 +327,22 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
 //                          16-byte non-temporal loads: A is streamed once per column)
 //                          x one column chunk; the 4 waves of a workgroup read 4 KiB
 //                          contiguous per column.
-template <int UNROLL, bool ALIGNED, bool STREAM = true>
+// SHARD (block-column sharded reduction, hessenberg_sharded_device): the workgroup that finishes a row
+// tile LAST adds the tile's column-split partials up into ysum -- the vector the ranks all-reduce --
+// so that no launch of its own stands between the gemv and the collective.  Hand-off without
+// fences (MI355X_MICROARCH.md, inter-workgroup visibility): every partial is stored and loaded
+// with agent-scope (sc1) accesses, the stores are drained before the workgroup takes its ticket.
+template <int UNROLL, bool ALIGNED, bool STREAM = true, bool SHARD = false>
 __global__ __launch_bounds__(256)
 void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double const *__restrict__ P, int R0, int E, int j, int cols_per_split, int ldp,
     int nshadow, int row_tiles,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
-    double *__restrict__ acc, double *__restrict__ scal, int world, int rank)
+    double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
+    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr)
 {
     __shared__ double s_wv[MAXJ], s_t[NGS][RBS + 1], s_scal[2];
+    __shared__ int s_last;
     int const piv = R0 + j, par = j & 1;
     double const *__restrict__ pcol = P + (size_t)j * ldp;
 
@@ -404,13 +411,14 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
         // row tiles start on a 128-byte line of A (tiles that straddle lines stream slower); the
         // up to 15 rows above R0 are read and dropped
         int const g = (R0 & ~15) + tile * GEMV_ROWS + threadIdx.x * 2;
-        if (g >= E) return;
+        if (!SHARD && g >= E) return;
         // y = A(:,piv) + scale * A(:,piv+1:) p''(piv+1:): the sum runs over the UNSCALED column (its
         // entries are uniform values that feed the FMAs straight from scalar registers: 60 VGPRs,
         // 8 waves per SIMD -- with the products scale*p'' held in vector registers it was 118 and the
         // 5 workgroups per CU of the launch did not fit at once), and the reflector scalars are
         // needed at the very end only, so no block waits for them before it starts to stream.
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, f0 = 0.0, f1 = 0.0;
+        if (g < E) {
         double const *a = A + (size_t)c_begin * ldA + g;
         int c = c_begin;
         if (c == piv) {
@@ -438,10 +446,35 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             a0 += x.x * v0; a1 += x.y * v0;
             a += ldA;
         }
+        }
         double scale, tau, beta;
         reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
-        if (g >= R0) yp[g] = f0 + scale * (a0 + b0);
-        if (g + 1 >= R0 && g + 1 < E) yp[g + 1] = f1 + scale * (a1 + b1);
+        if (!SHARD) {
+            if (g >= R0) yp[g] = f0 + scale * (a0 + b0);
+            if (g + 1 >= R0 && g + 1 < E) yp[g + 1] = f1 + scale * (a1 + b1);
+        } else {
+            if (g >= R0 && g < E) __hip_atomic_store(yp + g, f0 + scale * (a0 + b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g + 1 >= R0 && g + 1 < E) __hip_atomic_store(yp + g + 1, f1 + scale * (a1 + b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int const nsplit = ((int)gridDim.x - nshadow) / row_tiles;
+            if (threadIdx.x == 0)
+                s_last = __hip_atomic_fetch_add(tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+            __syncthreads();
+            if (s_last) {
+                #pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    int const gg = g + q;
+                    if (gg >= R0 && gg < E) {
+                        double sum = 0.0;
+                        for (int sp = 0; sp < nsplit; sp++)
+                            sum += __hip_atomic_load(ypart + (size_t)sp * ldp + gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ysum[gg] = sum;
+                    }
+                }
+                if (threadIdx.x == 0) __hip_atomic_store(tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     } else {
         // odd leading dimension / unaligned base: 8-byte loads
         for (int q = 0; q < 2; q++) {
@@ -482,6 +515,8 @@ struct HessWorkspace {
     double *P = nullptr, *YVW[2] = {nullptr, nullptr}, *VT[2] = {nullptr, nullptr};
     double *S = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
+    static constexpr int MAX_ROW_TILES = 256;   // row tiles of a gemv launch (512 rows each): n <= 131072
+    int *tile_cnt = nullptr;                    // sharded gemv: arrivals per row tile (self-resetting)
     hipStream_t side = nullptr, main = nullptr;
     hipEvent_t entry = nullptr;
     hipEvent_t panel_done[2] = {nullptr, nullptr}, side_done[2] = {nullptr, nullptr};
@@ -493,6 +528,7 @@ struct HessWorkspace {
     void release() {
         double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
+        if (tile_cnt) { SN_HIP_CHECK(hipFree(tile_cnt)); tile_cnt = nullptr; }
         n = nbmax = 0; ysplits = 0;
     }
     void ensure(int n_, int nb_) {
@@ -514,6 +550,8 @@ struct HessWorkspace {
         alloc(&ypart, (size_t)ysplits * ldp * sizeof(double));
         alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
         alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
+        SN_HIP_CHECK(hipMalloc((void **)&tile_cnt, sizeof(int) * MAX_ROW_TILES));
+        SN_HIP_CHECK(hipMemset(tile_cnt, 0, sizeof(int) * MAX_ROW_TILES));
         if (!side) {
             int lo = 0, hi = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest
@@ -763,6 +801,19 @@ __global__ void hess_zero_unowned_kernel(int mode, int n, double *__restrict__ X
     }
 }
 
+// rows [r_lo, r_hi) of columns [c0, c0 + nc) of X <-> a contiguous (r_hi - r_lo) x nc block (dir 0: pack, 1: unpack)
+__global__ void hess_pack_rows_kernel(int dir, int r_lo, int r_hi, int c0, int nc, double *__restrict__ X, int ld,
+    double *__restrict__ buf)
+{
+    int const rows = r_hi - r_lo;
+    int const r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (int c = blockIdx.y; c < nc; c += gridDim.y) {
+        double *x = X + (size_t)(c0 + c) * ld + r_lo + r, *b = buf + (size_t)c * rows + r;
+        if (dir == 0) *b = *x; else *x = *b;
+    }
+}
+
 int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ,
     double *dYsum, double *dP, double *dW2, long w2_capacity,
@@ -782,39 +833,52 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     int const qchunk = (int)roundup(divceil(n, world), 128);
     int const q_lo = std::min(n, rank * qchunk), q_hi = std::min(n, (rank + 1) * qchunk);
     if ((long)n * panel_width > w2_capacity) return -1;
+    // with one rank there is nothing to reduce: the column chain reads the gemv's partials directly
+    bool const reduce_y = world > 1;
+    if (reduce_y && aligned) SN_HIP_CHECK(hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * HessWorkspace::MAX_ROW_TILES, s));
 
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
     int pcount = 0;
-    double *Ys = ws.YVW[0], *V = Ys + (size_t)ldp * panel_width, *Ws = V + (size_t)ldp * panel_width, *VT = ws.VT[0];
     for (int i = begin; i < end - 1; i += panel_width, pcount++) {
         int const nb = std::min(panel_width, end - i - 1);
         int const R0 = i + 1, E = end, m = E - R0;
         int const nwg = divceil(m, RB);
         int const owner = (i / cb) % world;
+        int const buf = pcount & 1;
+        // [Y | V | W] and VT of the panel alternate between two buffers: the Q update of panel p runs on
+        // the side stream while panel p + 1 is factorised
+        double *Ys = ws.YVW[buf], *V = Ys + (size_t)ldp * nb, *Ws = V + (size_t)ldp * nb, *VT = ws.VT[buf];
+        if (pcount >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.side_done[buf], 0));
 
         SN_HIP_CHECK(hipMemsetAsync(ws.acc, 0, (size_t)ACC_TOTAL * sizeof(double), s));
         // panel columns from their owner (the caller's dP is the panel buffer of every rank)
         hipLaunchKernelGGL(hess_copy_in_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, dP, ldp);
-        comm.broadcast(comm.ctx, 1, 0, (long)ldp * nb, owner);
+        if (world > 1) comm.broadcast(comm.ctx, 1, 0, (long)ldp * nb, owner);
 
-        // owned column blocks that intersect [piv, E): splits of the sharded gemv
+        int nsplit = 0;
         for (int j = 0; j < nb; j++) {
             int const piv = R0 + j;
+            double const *ysrc = reduce_y ? dYsum : ws.ypart;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, dP, V, VT, Ys, dYsum, 1, ws.acc, ws.scal);
+                    R0, E, j, ldp, dP, V, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, dP, V, ws.acc);
+            // owned column blocks that intersect [piv, E): the splits of this rank's share of the gemv
             int const b0 = piv / cb;
             int const first = b0 + ((rank - b0 % world) + world) % world;
             int const last_block = (E - 1) / cb;
-            int nsplit = first > last_block ? 0 : (last_block - first) / world + 1;
+            nsplit = first > last_block ? 0 : (last_block - first) / world + 1;
             int const row_tiles = divceil(E - (R0 & ~15), GEMV_ROWS);
             int const nshadow = divceil(m, RBS);
-            if (nsplit > ws.ysplits) return -2;        // (cannot happen: one slice per block column)
-            dim3 grid(nshadow + row_tiles * std::max(nsplit, 0));
-            if (aligned)
+            if (nsplit > ws.ysplits || row_tiles > HessWorkspace::MAX_ROW_TILES) return -2;
+            dim3 grid(nshadow + row_tiles * nsplit);
+            if (aligned && reduce_y)
+                hipLaunchKernelGGL((hess_gemv_kernel<16, true, true, true>), grid, dim3(256), 0, s,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    world, rank, dYsum, ws.tile_cnt);
+            else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
                     world, rank);
@@ -822,68 +886,111 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                 hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
                     world, rank);
-            hipLaunchKernelGGL(hess_ysum_kernel, dim3(divceil(m, 256)), dim3(256), 0, s,
-                R0, E, nsplit, ldp, ws.ypart, dYsum);
-            comm.allreduce_sum(comm.ctx, 0, R0, (long)m);
+            if (reduce_y) {
+                if (nsplit == 0) SN_HIP_CHECK(hipMemsetAsync(dYsum + R0, 0, (size_t)m * sizeof(double), s));
+                else if (!aligned)
+                    hipLaunchKernelGGL(hess_ysum_kernel, dim3(divceil(m, 256)), dim3(256), 0, s,
+                        R0, E, nsplit, ldp, ws.ypart, dYsum);
+                comm.allreduce_sum(comm.ctx, 0, R0, (long)m);
+            }
             gemv_launches++;
             gemv_bytes += 8.0 * (double)m * (double)(E - piv) / world;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
-            R0, E, nb, ldp, dP, V, Ys, dYsum, 1, ws.acc, ws.scal);
+            R0, E, nb, ldp, dP, V, Ys, reduce_y ? dYsum : ws.ypart, reduce_y ? 1 : nsplit, ws.acc, ws.scal);
 
-        // trailing updates on the owned blocks right of the panel (core.c:523-547)
-        for (int B = (i + nb) / cb; B * cb < E; B++) {
-            if (B % world != rank) continue;
-            int const c0 = std::max(B * cb, i + nb), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+        // fused trailing update (hessenberg_device) on every run of adjacent owned blocks right of the panel
+        // (one run when this rank owns everything; single blocks otherwise):
+        //   W = At^T VT - V' (Y^T VT);   At <- At - [Y V] [V' W]^T              (core.c:523-547)
+        bool have_s = false;
+        for (int B = (i + nb) / cb; B * cb < E; ) {
+            if (B % world != rank) { B++; continue; }
+            int B1 = B + 1;
+            while (B1 * cb < E && B1 % world == rank) B1++;
+            int const c0 = std::max(B * cb, i + nb), c1 = std::min(E, B1 * cb), nt = c1 - c0;
+            B = B1;
             if (nt <= 0) continue;
+            if (!have_s) {
+                dgemm(s, 'T', 'N', nb, nb, m, 1.0, Ys + R0, ldp, VT + R0, ldp, 0.0, ws.S, nb);
+                gemm_flops += 2.0 * nb * (double)nb * m; have_s = true;
+            }
             double *At = dA + (size_t)c0 * ldA + R0;
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, Ys + R0, ldp, V + c0, ldp, 1.0, At, ldA);
-            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, Ws, ldp);
-            dgemm(s, 'N', 'T', m, nt, nb, -1.0, V + R0, ldp, Ws, ldp, 1.0, At, ldA);
-            gemm_flops += 6.0 * m * (double)nt * nb;
+            double *Wt = Ws + c0, *Vp = V + c0;                  // rows of W, V' <-> columns of At
+            dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, Wt, ldp);
+            dgemm(s, 'N', 'N', nt, nb, nb, -1.0, Vp, ldp, ws.S, nb, 1.0, Wt, ldp);
+            dgemm(s, 'N', 'T', m, nt, 2 * nb, -1.0, Ys + R0, ldp, Vp, ldp, 1.0, At, ldA);
+            gemm_flops += 6.0 * m * (double)nt * nb + 2.0 * nb * (double)nb * nt;
         }
         // every rank stores the finished panel columns (rows >= R0 are final)
         hipLaunchKernelGGL(hess_copy_out_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, dP, ldp);
 
         // rows above the panel: W = sum over owned blocks A(0:R0, blk) VT(blk,:), all-reduce,
-        // A(0:R0, blk) -= W V(blk,:)^T   (core.c:321-327)
+        // A(0:R0, blk) -= W V(blk,:)^T   (core.c:321-327).  On the critical stream: the collective
+        // callbacks act on the caller's stream.
         {
-            SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), s));
-            for (int B = R0 / cb; B * cb < E; B++) {
-                if (B % world != rank) continue;
-                int const c0 = std::max(B * cb, R0), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+            bool first_run = true;
+            for (int B = R0 / cb; B * cb < E; ) {
+                if (B % world != rank) { B++; continue; }
+                int B1 = B + 1;
+                while (B1 * cb < E && B1 % world == rank) B1++;
+                int const c0 = std::max(B * cb, R0), c1 = std::min(E, B1 * cb), nt = c1 - c0;
+                B = B1;
                 if (nt <= 0) continue;
-                dgemm(s, 'N', 'N', R0, nb, nt, 1.0, dA + (size_t)c0 * ldA, ldA, VT + c0, ldp, 1.0, dW2, R0);
+                dgemm(s, 'N', 'N', R0, nb, nt, 1.0, dA + (size_t)c0 * ldA, ldA, VT + c0, ldp, first_run ? 0.0 : 1.0, dW2, R0);
+                first_run = false;
                 gemm_flops += 2.0 * R0 * (double)nt * nb;
             }
-            comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
-            for (int B = R0 / cb; B * cb < E; B++) {
-                if (B % world != rank) continue;
-                int const c0 = std::max(B * cb, R0), c1 = std::min(E, (B + 1) * cb), nt = c1 - c0;
+            if (first_run) SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), s));
+            if (world > 1) comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
+            for (int B = R0 / cb; B * cb < E; ) {
+                if (B % world != rank) { B++; continue; }
+                int B1 = B + 1;
+                while (B1 * cb < E && B1 % world == rank) B1++;
+                int const c0 = std::max(B * cb, R0), c1 = std::min(E, B1 * cb), nt = c1 - c0;
+                B = B1;
                 if (nt <= 0) continue;
                 dgemm(s, 'N', 'T', R0, nt, nb, -1.0, dW2, R0, V + c0, ldp, 1.0, dA + (size_t)c0 * ldA, ldA);
                 gemm_flops += 2.0 * R0 * (double)nt * nb;
             }
         }
-        // Q: this rank's row block (core.c:339-340), no communication
+        SN_HIP_CHECK(hipEventRecord(ws.panel_done[buf], s));
+        // Q: this rank's row block (core.c:339-340), no communication: on the side stream, beside the next panel
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.side, ws.panel_done[buf], 0));
         if (dQ && q_hi > q_lo) {
             int const rows = q_hi - q_lo;
             double *X = dQ + (size_t)R0 * ldQ + q_lo;
-            dgemm(s, 'N', 'N', rows, nb, m, 1.0, X, ldQ, VT + R0, ldp, 0.0, ws.W2, ldp);
-            dgemm(s, 'N', 'T', rows, m, nb, -1.0, ws.W2, ldp, V + R0, ldp, 1.0, X, ldQ);
+            dgemm(ws.side, 'N', 'N', rows, nb, m, 1.0, X, ldQ, VT + R0, ldp, 0.0, ws.W2, ldp);
+            dgemm(ws.side, 'N', 'T', rows, m, nb, -1.0, ws.W2, ldp, V + R0, ldp, 1.0, X, ldQ);
             gemm_flops += 4.0 * rows * (double)m * nb;
         }
+        SN_HIP_CHECK(hipEventRecord(ws.side_done[buf], ws.side));
     }
-    // assemble H and Q on every rank
+    for (int k = 0; k < 2 && k < pcount; k++)
+        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.side_done[k], 0));
+    // assemble H and Q on every rank: every piece travels once, from its owner (an all-gather written as
+    // broadcasts: the block columns of A are contiguous; the row blocks of Q go through dW2 in chunks of
+    // columns) -- instead of zeroing the rest and all-reducing two full matrices
     if (world > 1) {
-        hipLaunchKernelGGL(hess_zero_unowned_kernel, dim3(divceil(n, 256), std::min(n, 1024)), dim3(256), 0, s,
-            0, n, dA, ldA, cb, world, rank, 0, 0);
-        comm.allreduce_sum(comm.ctx, 3, 0, (long)ldA * n);
+        for (int B = 0; B * cb < n; B++) {
+            int const c0 = B * cb, c1 = std::min(n, c0 + cb);
+            comm.broadcast(comm.ctx, 3, (long)c0 * ldA, (long)(c1 - c0) * ldA, B % world);
+        }
         if (dQ) {
-            hipLaunchKernelGGL(hess_zero_unowned_kernel, dim3(divceil(n, 256), std::min(n, 1024)), dim3(256), 0, s,
-                1, n, dQ, ldQ, cb, world, rank, q_lo, q_hi);
-            comm.allreduce_sum(comm.ctx, 4, 0, (long)ldQ * n);
+            for (int root = 0; root < world; root++) {
+                int const r_lo = std::min(n, root * qchunk), r_hi = std::min(n, (root + 1) * qchunk), rows = r_hi - r_lo;
+                if (rows <= 0) continue;
+                int const chunk = (int)std::min<long>(n, w2_capacity / rows);
+                for (int c0 = 0; c0 < n; c0 += chunk) {
+                    int const nc = std::min(chunk, n - c0);
+                    dim3 const grid(divceil(rows, 256), std::min(nc, 1024));
+                    if (root == rank)
+                        hipLaunchKernelGGL(hess_pack_rows_kernel, grid, dim3(256), 0, s, 0, r_lo, r_hi, c0, nc, dQ, ldQ, dW2);
+                    comm.broadcast(comm.ctx, 2, 0, (long)rows * nc, root);
+                    if (root != rank)
+                        hipLaunchKernelGGL(hess_pack_rows_kernel, grid, dim3(256), 0, s, 1, r_lo, r_hi, c0, nc, dQ, ldQ, dW2);
+                }
+            }
         }
     }
     if (tm) {

@@ -460,7 +460,11 @@ struct SchurWorkspace {
                 SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&hs, words, mask.data()));
             } else {
                 SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
-                SN_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, lo_prio));
+                // the lazy H stream -- the one the critical stream waits for at the start of every sweep --
+                // one level above the lazy Q stream, which nobody waits for before the end (measured at
+                // n = 20000: 2.60 s against 2.70 s with both at the lowest priority)
+                int const hs_prio = tuning().schur_hs_prio ? std::max(hi_prio, lo_prio - 1) : lo_prio;
+                SN_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, hs_prio));
             }
             for (int k = 0; k < EV_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
@@ -882,7 +886,7 @@ struct Driver {
     std::vector<SweepStep> agg_steps_;
     double agg_extra_flops = 0.0;
     double prof_agg_plan = 0, prof_agg_desc = 0, prof_agg_launch = 0; long prof_agg_tiles = 0, prof_agg_flushes = 0, prof_agg_launches = 0;
-    void flush_lazy_aggregated(int col_split)
+    void flush_lazy_aggregated(std::vector<LazyItem> const &lazy, int col_split, bool do_h, bool do_q)
     {
         double const tp0 = wall();
         agg_steps_.clear();
@@ -914,8 +918,8 @@ struct Driver {
             std::memcpy(descs, tiles, (size_t)cnt * sizeof(AggTile));
             prof_agg_desc += wall() - td0;
             double const tl0 = wall();
-            if (agg_h) hipLaunchKernelGGL(agg_build_kernel, dim3(AGG_W / AGG_SLAB, cnt), dim3(256), AGG_BUILD_LDS, ws.hs, descs);
-            for (int v = w; v < w1 && agg_h; v++) {
+            if (do_h) hipLaunchKernelGGL(agg_build_kernel, dim3(AGG_W / AGG_SLAB, cnt), dim3(256), AGG_BUILD_LDS, ws.hs, descs);
+            for (int v = w; v < w1 && do_h; v++) {
                 int const b = agg_plan_.wave_begin[v] - t0, e = agg_plan_.wave_begin[v + 1] - t0;
                 int max_rs = 0, max_left = 0, maxW = 0;
                 for (int k = b; k < e; k++) {
@@ -928,7 +932,7 @@ struct Driver {
                 if (max_rs > 0) agg_launch_right(ws.hs, maxW, divceil(max_rs, AGG_BM), e - b, descs + b, H, ldH, 0, 1);
                 if (lazy_cols > 0) agg_launch_left(ws.hs, maxW, divceil(lazy_cols, AGG_BM), e - b, descs + b, H, ldH, col_split, n);
             }
-            if (Q) {
+            if (do_q) {
                 AggTile *descsq = agg_descs(cnt);
                 for (int k = 0; k < cnt; k++) agg_plan_.tiles[t0 + k].G = ws.dAggGq + (size_t)k * AGG_W * AGG_W;
                 std::memcpy(descsq, tiles, (size_t)cnt * sizeof(AggTile));
@@ -949,7 +953,17 @@ struct Driver {
         for (AggTile const &t : agg_plan_.tiles) {
             double std_flops = 0.0;
             for (int i = 0; i < t.nfac; i++) std_flops += 2.0 * t.f[i].n * t.f[i].n;
-            agg_extra_flops += (2.0 * t.W * t.W - std_flops) * ((Q ? nq : 0) + (agg_h ? (double)t.rs + lazy_cols : 0.0));
+            agg_extra_flops += (2.0 * t.W * t.W - std_flops) * ((do_q ? nq : 0) + (do_h ? (double)t.rs + lazy_cols : 0.0));
+        }
+    }
+
+    void launch_q(std::vector<LazyItem> const &items)
+    {
+        for (LazyItem const &it : items) {
+            double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
+            // (64-row tiles reach 13 % more of the HBM rate alone, scratch/update_bench.py, but change nothing in situ)
+            hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(nq, 128), it.step.ntasks),
+                dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, nq, Ubuf, 0, nq);
         }
     }
 
@@ -962,8 +976,9 @@ struct Driver {
         SN_HIP_CHECK(hipStreamWaitEvent(ws.hs, ws.far_done[last_ev], 0));
         if (Q) SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.near_done[last_ev], 0));
         bool const aggregate = agg_on && lazy.size() >= 8 && agg_geometry_ok(lazy.front().step);
+        bool const agg_hpart = aggregate && agg_h;
         for (LazyItem const &it : lazy) {
-            if (!aggregate || !agg_h) {
+            if (!agg_hpart) {
                 int const ntasks = it.step.ntasks;
                 double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
                 int const lazy_cols = n - col_split, lazy_rows = it.row_split;
@@ -971,14 +986,11 @@ struct Driver {
                     hipLaunchKernelGGL(schur_update_pair_kernel,
                         dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
                         UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
-                if (Q && !aggregate)
-                    // (64-row tiles reach 13 % more of the HBM rate alone, scratch/update_bench.py, but change nothing in situ)
-                    hipLaunchKernelGGL(schur_update_kernel<3>, dim3(divceil(nq, 128), ntasks),
-                        dim3(256), UPDATE_LDS_BYTES_R, ws.qs, it.step, H, ldH, Q, ldQ, nq, Ubuf, 0, nq);
             }
             ws.slot_flush[it.ev] = ws.flush_total;
         }
-        if (aggregate) flush_lazy_aggregated(col_split);
+        if (aggregate) flush_lazy_aggregated(lazy, col_split, agg_hpart, Q != nullptr);
+        else if (Q) launch_q(lazy);
         SN_HIP_CHECK(hipEventRecord(ws.h_done[fslot], ws.hs));
         if (Q) SN_HIP_CHECK(hipEventRecord(ws.q_done[fslot], ws.qs));
         ws.flush_total++;
@@ -1002,7 +1014,7 @@ struct Driver {
     int spw_cap = -1;           // conf->shifts_per_window (process_args.c:418-437)
     long chain_passes = 0;      // chains over all sweeps: the rounding error grows like its square root
     int lazy_batch = tuning().schur_lazy_batch;
-    bool agg_on = tuning().schur_aggregate != 0;
+    bool agg_on = tuning().schur_aggregate > 0;
     bool agg_h = tuning().schur_aggregate != 2;         // 2: aggregate the Q updates only
 
     void sweep_begin(int ilo, int ihi, int nshifts, double const *sr, double const *si)

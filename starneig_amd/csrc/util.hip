@@ -30,6 +30,7 @@ Tuning const &tuning()
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_aggregate = geti("SN_SCHUR_AGG", t.schur_aggregate);
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);
+        t.schur_hs_prio = geti("SN_SCHUR_HS_PRIO", 1) != 0;
         t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
         t.gep_serial = getb("SN_GEP_SERIAL");

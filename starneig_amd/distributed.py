@@ -13,7 +13,8 @@ Communication per reduction of an n x n matrix with panel width nb (SURVEY.md 8e
   per panel : broadcast of the owner's panel columns  (ld*nb doubles)
               all-reduce of W = A(0:i+1, .) V T        ((i+1)*nb doubles)
   per column: all-reduce of the partial y = A v        (<= n doubles)
-  at the end: assembly of A and Q                      (2 * ld*n doubles)
+  at the end: assembly of A and Q: every block column of A and every row block of Q is broadcast
+              once by its owner (an all-gather: (N-1)/N of 2 * ld*n doubles arrive at each rank)
 """
 import ctypes as C
 import os
@@ -170,8 +171,8 @@ def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
 def schur_sharded(tH, tQ, n=None, conf=None, group=None):
     """Schur reduction of the Hessenberg matrix every rank holds (identically) in tH: each rank
     reduces its replica of H -- the reduction is deterministic, the replicas stay bit-identical,
-    no communication -- but accumulates only its row block of Q (45 % of the update flops of
-    the leg); Q is assembled at the end (zero the rows of other ranks, all-reduce).
+    no communication -- but accumulates only its row block of Q (half of the update flops of
+    the leg); Q is assembled at the end by one all-gather of the row blocks.
     Returns (rc, real, imag, stats)."""
     import numpy as np
     import torch
@@ -202,9 +203,18 @@ def schur_sharded(tH, tQ, n=None, conf=None, group=None):
         if not torch.equal(lo, hi):
             raise RuntimeError("starneig_amd: the replicas of H diverged in the sharded Schur leg "
                                f"(checksums {lo.tolist()} .. {hi.tolist()})")
-        tQ[:, :r0] = 0.0
-        tQ[:, r1:] = 0.0
-        dist.all_reduce(tQ, op=dist.ReduceOp.SUM, group=group)
+        # all-gather of the row blocks (every row travels once, from its owner) -- not "zero the
+        # rest and all-reduce the whole matrix", which moves twice the bytes through every rank
+        chunk = owned_q_rows(n, world, 0)[1]
+        send = torch.zeros((n, chunk), dtype=torch.float64, device=tQ.device)
+        send[:, :r1 - r0] = tQ[:n, r0:r1]
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
+        for k in range(world):
+            a, b = owned_q_rows(n, world, k)
+            if k != rank and b > a:
+                tQ[:n, a:b] = recv[k][:, :b - a]
+        del send, recv
     stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
              "aed_host_s": st[6], "gpu_wait_s": st[7], "q_rows": (r0, r1)}
