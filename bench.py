@@ -30,10 +30,10 @@ MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (spec; SURVEY.md secti
 
 def pmc_traffic_ratio():
     """HBM traffic / algorithmic bytes of the panel gemv from the committed PMC passes
-    (profiles/r2_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    (profiles/r3_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_gemv_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_gemv_pmc_traffic.json")) as f:
             return json.load(f)["traffic_over_algorithmic"]
     except Exception:
         return None
@@ -98,6 +98,40 @@ def run_qz(S, n, kind, steps, warmup):
            "qz_sweeps": st["sweeps"], "aeds": st["aeds"], "aed_host_s": st["aed_host_s"]}
     del tH0, tR0, tQ, tZ
     torch.cuda.empty_cache()
+    return out
+
+
+def run_gep_chain(S, n):
+    """starneig_GEP_SM_Reduce's two steps on a GENERAL pencil (two LCG matrices), device resident: the
+    Hessenberg-triangular reduction, then QZ of its output -- a pencil on which the QZ sweeps (not only
+    the AED windows) carry the reduction.  One timed run after a small warm-up of the workspaces."""
+    import torch
+    out = None
+    for m in (1000, n):
+        tA, tB = S.device_matrix(m), S.device_matrix(m)
+        S.lcg_fill_device(tA, m, m, seed=2019); S.lcg_fill_device(tB, m, m, seed=77)
+        tA0, tB0 = tA.clone(), tB.clone()
+        tQ, tZ = S.device_matrix(m), S.device_matrix(m)
+        S.set_matrix_device(tQ, m, m, 0.0, 1.0); S.set_matrix_device(tZ, m, m, 0.0, 1.0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=m)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        assert rc == 0, rc
+        rc, ar, ai, be, st2 = S.gep_schur_device(tA, tB, tQ, tZ, n=m)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        assert rc == 0, rc
+        _, ca = S.check_pencil_device(tQ, tA, tZ, tA0, n=m)
+        _, cb = S.check_pencil_device(tQ, tB, tZ, tB0, n=m)
+        out = {"pencil": "general (LCG seeds 2019 / 77): Hessenberg-triangular reduction, then QZ", "n": m,
+               "hessenberg_triangular_s": t1 - t0, "qz_s": t2 - t1,
+               "ns_per_chain_rotation": st["rotation_ms"] * 1e6 / max(st["rotations"] / 2, 1),
+               "qz_sweeps": st2["sweeps"], "aeds": st2["aeds"], "aed_host_s": st2["aed_host_s"],
+               "qz_executed_gemm_tflop": st2["gemm_flops"] / 1e12,
+               "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
+               "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
+               "below_subdiagonal_nonzeros": ca["below_subdiagonal"]}
+        del tA, tB, tA0, tB0, tQ, tZ
+        torch.cuda.empty_cache()
     return out
 
 
@@ -340,6 +374,31 @@ def host_api_call(S, n):
             "gflops": (hess_flops(n) + schur_flops(n)) / (t2 - t0) / 1e9}
 
 
+def secondary_in_child():
+    """The secondary workloads run in a child process of their own (started here, relayed, never exec'ed):
+    the stream set-up the Hessenberg-triangular reduction is tuned for is the one of a fresh process -- after
+    the Schur and QZ legs have created their ~20 priority streams the same reduction runs at half the rate
+    (the runtime multiplexes streams onto a few hardware queues)."""
+    import subprocess
+    proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "secondary"],
+                          capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("[")]
+    if proc.returncode != 0 or not lines:
+        return {"error": f"secondary child failed (rc {proc.returncode})", "stderr_tail": proc.stderr[-600:]}
+    return json.loads(lines[-1])
+
+
+def bench_secondary(args):
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")
+    import starneig_amd as S
+    S.node_init(S.USE_ALL, 1, S.NO_MESSAGES)
+    out = [run_gep_chain(S, 8000), run_qz(S, 12000, "lcg", 1, 1), run_qz(S, 12000, "wellcond", 1, 1)]
+    S.node_finalize()
+    print(json.dumps(out), flush=True)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as a CHILD
     process (torch.distributed.run, one rank per GPU) before anything here touches the GPU, relay
@@ -371,7 +430,7 @@ def main():
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded Hessenberg path even at N=1 (exercises the collectives)")
-    ap.add_argument("--workload", choices=["sep", "qz", "ht"], default="sep",
+    ap.add_argument("--workload", choices=["sep", "qz", "ht", "secondary"], default="sep",
                     help="sep = Hessenberg + Schur (the headline metric); qz = BASELINE config 5; "
                          "ht = Hessenberg-triangular reduction (the step before config 5)")
     ap.add_argument("--cpu-ht-n", type=int, default=1500,
@@ -380,7 +439,8 @@ def main():
                     help="qz workload: the test driver's pencil (config 5) or its well-conditioned variant")
     ap.add_argument("--secondary", type=int, default=1,
                     help="1: append the QZ legs (config 5 and the well-conditioned pencil, n=12000, one timed "
-                         "step each) to the default line as `secondary`, N=1 only")
+                         "step each) and the generalized chain (Hessenberg-triangular + QZ, n=8000) to the "
+                         "default line as `secondary`, N=1 only")
     ap.add_argument("--sample-every", type=int, default=16,
                     help="time every k-th panel-gemv launch with HIP events")
     args = ap.parse_args()
@@ -388,6 +448,8 @@ def main():
         return bench_qz(args)
     if args.workload == "ht":
         return bench_ht(args)
+    if args.workload == "secondary":
+        return bench_secondary(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -419,7 +481,7 @@ def main():
 
     import starneig_amd as S
     from starneig_amd import distributed as D
-    S.node_init(1, 1, S.NO_MESSAGES)
+    S.node_init(S.USE_ALL, 1, S.NO_MESSAGES)     # cores: the staging threads of the host-array API use up to 8
 
     n = args.n
     tA0 = S.device_matrix(n)
@@ -441,7 +503,8 @@ def main():
         if sharded:
             rc, st = D.hessenberg_sharded(tA, tQ, n=n)
             st.update({"gemv_sampled_ms": 0.0, "gemv_sampled_bytes": 0.0, "gemv_sampled_launches": 0,
-                       "gemm_main_ms": 0.0, "gemm_main_flops": 0.0, "gemm_side_ms": 0.0})
+                       "gemm_main_ms": 0.0, "gemm_main_flops": 0.0, "gemm_side_ms": 0.0,
+                       "gemm_fused_ms": 0.0, "gemm_fused_flops": 0.0})
         else:
             rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True, sample_every=sample_every)
         torch.cuda.synchronize()
@@ -520,7 +583,7 @@ def main():
                 "traffic": (ratio * sb / nl) if (ratio and nl) else None,
                 "traffic_note": "avg algorithmic bytes per launch x PMC ratio "
                                 "(2*FETCH_SIZE+WRITE_SIZE)/algorithmic measured on the 624 launches of "
-                                "the first two panels at n=20000, profiles/r2_gemv_pmc_traffic.json",
+                                "the first two panels at n=20000, profiles/r3_gemv_pmc_traffic.json",
                 "launches_timed": nl,
                 "avg_launch_us": (sm / nl * 1e3) if nl else None,
                 "avg_launch_bytes": (sb / nl) if nl else None,
@@ -533,15 +596,22 @@ def main():
         gf = sum(s["gemm_main_flops"] for s in stats)
         gs = sum(s["gemm_side_ms"] for s in stats)
         gfs = sum(s["gemm_flops"] - s["gemm_main_flops"] for s in stats)
-        if gm > 0:
-            tf = gf / (gm * 1e-3) / 1e12
+        fm = sum(s["gemm_fused_ms"] for s in stats)
+        ff = sum(s["gemm_fused_flops"] for s in stats)
+        if gm > 0 and fm > 0:
+            tf = ff / (fm * 1e-3) / 1e12
+            tfc = gf / (gm * 1e-3) / 1e12
             out["roofline_mfma"] = {
-                "kernel": "dgemm_kernel<128,128,16,N,T> + split-K W product (trailing update, rows H4-H6)",
+                "kernel": "dgemm_kernel<128,128,16,N,T>: the fused trailing update A -= [Y V][V' W]^T, k = 2 nb (rows H4, H6)",
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-                "flops_per_step": gf / args.steps, "ms_per_step": gm / args.steps,
+                "flops_per_step": ff / args.steps, "ms_per_step": fm / args.steps,
+                # the whole critical update: + the split-K W product (row H5), S = Y^T VT, W -= V' S, their memsets and gaps
+                "critical_update_tflops": tfc, "critical_update_frac": tfc / MFMA_F64_PEAK_TFLOPS,
+                "critical_update_ms_per_step": gm / args.steps,
                 "side_stream_tflops": (gfs / (gs * 1e-3) / 1e12) if gs > 0 else None,
-                "note": "in situ; standalone PMC utilisation of the same kernels in profiles/",
+                "note": "in situ, HIP events on the critical stream around every panel's launch(es); PMC MFMA-busy "
+                        "counters of the same kernels in situ: profiles/r3_pmc_mfma_in_situ.json",
             }
         if world == 1 and args.host_api:
             out["config"]["host_api_s"] = host_api_call(S, n)
@@ -550,7 +620,7 @@ def main():
         if world == 1 and args.secondary and not sharded:
             # driver-timed secondary workloads (not part of `value`): BASELINE config 5 and the same
             # size on a well-conditioned pencil, where the QZ sweeps -- not the host AED -- do the work
-            out["secondary"] = [run_qz(S, 12000, "lcg", 1, 1), run_qz(S, 12000, "wellcond", 1, 1)]
+            out["secondary"] = secondary_in_child()
 
     if sharded:
         from starneig_amd import distributed as _D

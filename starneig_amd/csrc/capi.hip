@@ -739,6 +739,7 @@ SN_API starneig_error_t starneig_amd_hessenberg_device(
         stats[3] = tm.sampled_ms; stats[4] = tm.sampled_bytes;
         stats[5] = (double)tm.gemv_launches; stats[6] = (double)tm.sampled_launches;
         stats[8] = tm.gemm_ms_main; stats[9] = tm.gemm_flops_main; stats[10] = tm.gemm_ms_side;
+        stats[11] = tm.gemm_ms_fused; stats[12] = tm.gemm_flops_fused;
     }
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 }

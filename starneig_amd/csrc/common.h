@@ -62,6 +62,8 @@ struct HessenbergTimings {
     double gemm_flops_main = 0.0;   // of which: the critical trailing update (rows H4-H6)
     double gemm_ms_main = 0.0;      // its summed duration (events on the critical stream)
     double gemm_ms_side = 0.0;      // summed duration of the delayed updates (Q, upper rows) on the side stream
+    double gemm_flops_fused = 0.0;  // of gemm_flops_main: the fused k = 2 nb update A -= [Y V][V' W]^T alone
+    double gemm_ms_fused = 0.0;     // its summed duration
     long gemv_launches = 0;
     long sampled_launches = 0;
     double sampled_bytes = 0.0; // algorithmic bytes of the sampled launches

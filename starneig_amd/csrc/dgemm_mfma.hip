@@ -61,10 +61,16 @@ void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
 {
     int const k0 = blockIdx.y * kchunk, kl = min(kchunk, k - k0);
     if (kl <= 0) return;
+    // Tile order (speed only): the few column tiles of ONE row panel go to the same XCD back to back
+    // (blocks b and b + 8 share an XCD), so the long operand panel -- 128 columns of the trailing matrix
+    // in W = At^T (V T) -- comes from HBM once and from that XCD's L2 for the other column tiles.
+    int const tiles_n = (n + BN - 1) / BN;
+    int const x = blockIdx.x % 8, j = blockIdx.x / 8;
+    int const bm = x + 8 * (j / tiles_n), bn = j % tiles_n;
+    if (bm >= tiles_m) return;
     double const *Ak = TA ? A + k0 : A + (size_t)k0 * lda;
     double const *Bk = TB ? B + (size_t)k0 * ldb : B + k0;
-    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc,
-        blockIdx.x % tiles_m, blockIdx.x / tiles_m, true);
+    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc, bm, bn, true);
 }
 
 // Batched form: blockIdx.y selects a problem descriptor (alpha = 1, beta = 0).  Used for the
@@ -141,7 +147,7 @@ static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double
         attr_set = true;
     }
     int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
-    int const tiles_m = divceil(m, BM), tiles = tiles_m * divceil(n, BN);
+    int const tiles_m = divceil(m, BM), tiles = 8 * divceil(tiles_m, 8) * divceil(n, BN);   // (rounded up: see the kernel's tile order)
     SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, divceil(k, kchunk)), dim3(256), Cfg::LDS_BYTES, s,
         m, n, k, kchunk, alpha, A, lda, B, ldb, C, ldc, tiles_m);

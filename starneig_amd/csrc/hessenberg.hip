@@ -600,7 +600,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
     ws.ensure(n, panel_width);
     int const ldp = ws.ldp;
     bool const aligned = (ldA % 2 == 0) && (((uintptr_t)dA) % 16 == 0);
-    double gemv_bytes = 0.0, gemm_flops = 0.0, gemm_flops_main = 0.0;
+    double gemv_bytes = 0.0, gemm_flops = 0.0, gemm_flops_main = 0.0, gemm_flops_fused = 0.0;
     long gemv_launches = 0;
     size_t nsampled = 0;
     int const sample_every = tm ? tm->sample_every : 0;
@@ -684,10 +684,10 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         // i.e. ONE read of At for W and ONE read-modify-write of At with k = 2 nb, instead of the
         // reference's right update, left product and left update (three passes, two of them RMW).
         if (timed) {
-            while (ws.gemm_ev.size() < 4 * (size_t)(pcount + 1)) {
+            while (ws.gemm_ev.size() < 6 * (size_t)(pcount + 1)) {
                 hipEvent_t e; SN_HIP_CHECK(hipEventCreate(&e)); ws.gemm_ev.push_back(e);
             }
-            SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 0], s));
+            SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 0], s));
         }
         int const nt = E - (i + nb);
         if (nt > 0) {
@@ -696,11 +696,16 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             dgemm(s, 'T', 'N', nt, nb, m, 1.0, At, ldA, VT + R0, ldp, 0.0, Wt, ldp);
             dgemm(s, 'T', 'N', nb, nb, m, 1.0, Y + R0, ldp, VT + R0, ldp, 0.0, ws.S, nb);
             dgemm(s, 'N', 'N', nt, nb, nb, -1.0, Vp, ldp, ws.S, nb, 1.0, Wt, ldp);
+            if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 4], s));
             dgemm(s, 'N', 'T', m, nt, 2 * nb, -1.0, Y + R0, ldp, Vp, ldp, 1.0, At, ldA);
+            if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 5], s));
             double const f = 6.0 * m * (double)nt * nb + 2.0 * nb * (double)nb * (m + nt);
-            gemm_flops += f; gemm_flops_main += f;
+            gemm_flops += f; gemm_flops_main += f; gemm_flops_fused += 4.0 * m * (double)nt * nb;
+        } else if (timed) {
+            SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 4], s));
+            SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 5], s));
         }
-        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 1], s));
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 1], s));
         // panel columns go back into A (core.c:317)
         hipLaunchKernelGGL(hess_copy_out_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, ws.P, ldp);
@@ -709,7 +714,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         // ---- non-critical updates on the side stream (core.c:321-340) ----
         hipStream_t q = tuning().hess_noside ? s : ws.side;
         SN_HIP_CHECK(hipStreamWaitEvent(q, ws.panel_done[buf], 0));
-        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 2], q));
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 2], q));
         {   // upper rows A(0:R0, R0:E) (I - V T V^T)
             double *X = dA + (size_t)R0 * ldA;
             dgemm(q, 'N', 'N', R0, nb, m, 1.0, X, ldA, VT + R0, ldp, 0.0, ws.W2, ldp);
@@ -729,7 +734,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             dgemm(q, 'N', 'T', n, m, nb, -1.0, ws.W2, ldp, V + R0, ldp, 1.0, X, ldQ);
             gemm_flops += 4.0 * n * (double)m * nb;
         }
-        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[4 * pcount + 3], q));
+        if (timed) SN_HIP_CHECK(hipEventRecord(ws.gemm_ev[6 * pcount + 3], q));
         SN_HIP_CHECK(hipEventRecord(ws.side_done[buf], q));
     }
     // join the side stream back into s
@@ -745,13 +750,16 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
         tm->gemv_bytes = gemv_bytes;
         tm->gemm_flops = gemm_flops;
         tm->gemm_flops_main = gemm_flops_main;
-        tm->gemm_ms_main = tm->gemm_ms_side = 0.0;
+        tm->gemm_ms_main = tm->gemm_ms_side = tm->gemm_ms_fused = 0.0;
+        tm->gemm_flops_fused = gemm_flops_fused;
         for (int p = 0; p < pcount; p++) {
             float t = 0.f;
-            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[4 * p], ws.gemm_ev[4 * p + 1]));
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[6 * p], ws.gemm_ev[6 * p + 1]));
             tm->gemm_ms_main += t;
-            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[4 * p + 2], ws.gemm_ev[4 * p + 3]));
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[6 * p + 2], ws.gemm_ev[6 * p + 3]));
             tm->gemm_ms_side += t;
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.gemm_ev[6 * p + 4], ws.gemm_ev[6 * p + 5]));
+            tm->gemm_ms_fused += t;
         }
         tm->gemv_launches = gemv_launches;
         tm->sampled_launches = (long)nsampled;
@@ -925,10 +933,14 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
         hipLaunchKernelGGL(hess_copy_out_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, dP, ldp);
 
+        SN_HIP_CHECK(hipEventRecord(ws.panel_done[buf], s));
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.side, ws.panel_done[buf], 0));
         // rows above the panel: W = sum over owned blocks A(0:R0, blk) VT(blk,:), all-reduce,
-        // A(0:R0, blk) -= W V(blk,:)^T   (core.c:321-327).  On the critical stream: the collective
-        // callbacks act on the caller's stream.
+        // A(0:R0, blk) -= W V(blk,:)^T   (core.c:321-327; delayed there too).  With one rank: on the side
+        // stream.  With several the all-reduce keeps it on the caller's stream: the collectives of one
+        // communicator are issued on one stream, in one order.
         {
+            hipStream_t const us = world == 1 ? ws.side : s;
             bool first_run = true;
             for (int B = R0 / cb; B * cb < E; ) {
                 if (B % world != rank) { B++; continue; }
@@ -937,11 +949,11 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                 int const c0 = std::max(B * cb, R0), c1 = std::min(E, B1 * cb), nt = c1 - c0;
                 B = B1;
                 if (nt <= 0) continue;
-                dgemm(s, 'N', 'N', R0, nb, nt, 1.0, dA + (size_t)c0 * ldA, ldA, VT + c0, ldp, first_run ? 0.0 : 1.0, dW2, R0);
+                dgemm(us, 'N', 'N', R0, nb, nt, 1.0, dA + (size_t)c0 * ldA, ldA, VT + c0, ldp, first_run ? 0.0 : 1.0, dW2, R0);
                 first_run = false;
                 gemm_flops += 2.0 * R0 * (double)nt * nb;
             }
-            if (first_run) SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), s));
+            if (first_run) SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), us));
             if (world > 1) comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
             for (int B = R0 / cb; B * cb < E; ) {
                 if (B % world != rank) { B++; continue; }
@@ -950,13 +962,12 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                 int const c0 = std::max(B * cb, R0), c1 = std::min(E, B1 * cb), nt = c1 - c0;
                 B = B1;
                 if (nt <= 0) continue;
-                dgemm(s, 'N', 'T', R0, nt, nb, -1.0, dW2, R0, V + c0, ldp, 1.0, dA + (size_t)c0 * ldA, ldA);
+                dgemm(us, 'N', 'T', R0, nt, nb, -1.0, dW2, R0, V + c0, ldp, 1.0, dA + (size_t)c0 * ldA, ldA);
                 gemm_flops += 2.0 * R0 * (double)nt * nb;
             }
         }
         SN_HIP_CHECK(hipEventRecord(ws.panel_done[buf], s));
         // Q: this rank's row block (core.c:339-340), no communication: on the side stream, beside the next panel
-        SN_HIP_CHECK(hipStreamWaitEvent(ws.side, ws.panel_done[buf], 0));
         if (dQ && q_hi > q_lo) {
             int const rows = q_hi - q_lo;
             double *X = dQ + (size_t)R0 * ldQ + q_lo;

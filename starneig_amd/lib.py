@@ -360,7 +360,8 @@ def hessenberg_device(tA, tQ, n=None, begin=0, end=None, panel_width=-1, stats=F
         return rc, {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
                     "gemv_sampled_ms": st[3], "gemv_sampled_bytes": st[4],
                     "gemv_launches": int(st[5]), "gemv_sampled_launches": int(st[6]),
-                    "gemm_main_ms": st[8], "gemm_main_flops": st[9], "gemm_side_ms": st[10]}
+                    "gemm_main_ms": st[8], "gemm_main_flops": st[9], "gemm_side_ms": st[10],
+                    "gemm_fused_ms": st[11], "gemm_fused_flops": st[12]}
     return rc
 
 
