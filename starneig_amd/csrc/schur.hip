@@ -708,9 +708,13 @@ struct Driver {
             hipMemcpyHostToDevice, ts));
     }
 
+    // where a blocked AED spends its time (SN_SCHUR_PROFILE): recursive Schur form of the window, deflation
+    // / reordering windows, re-Hessenberg of the undeflated part, the rest (copies, updates of H and Q)
+    double prof_laed[4] = {0, 0, 0, 0}; int prof_laed_calls = 0, prof_laed_windows = 0;
     host::AedResult large_aed(int kw, int nw, double sub, double thres, double *spike, double *sr, double *si)
     {
         host::AedResult res{0, 0, 0};
+        double const tl0 = wall(); prof_laed_calls++;
         LargeAedBuffers &L = g_large;
         L.ensure(nw);
         int const ld = L.ld;
@@ -722,6 +726,7 @@ struct Driver {
         std::vector<double> wr(nw), wi(nw);
         int const rc1 = schur_device(ts, nw, L.dT, ld, L.dZ, ld, wr.data(), wi.data(), SchurParams{}, nullptr, -1, 1);
         SN_HIP_CHECK(hipStreamSynchronize(ts));
+        double const tl1 = wall(); prof_laed[0] += tl1 - tl0;
         if (rc1 != STARNEIG_SUCCESS) {          // no usable Schur form: report the shifts we have, deflate nothing
             res.failed = 1;
             res.shifts = host::order_shifts(nw, wr.data(), wi.data());
@@ -743,7 +748,7 @@ struct Driver {
             int wb = std::max(top, we - WDD);
             if (wb > top && tsub[wb - 1] != 0.0) wb++;          // do not cut a 2x2 block
             int const w = we - wb, ldh = host_ld(w);
-            window_to_host(L, wb, w, ldh);
+            window_to_host(L, wb, w, ldh); prof_laed_windows++;
             int und = 0;
             int const rej = host::deflate_window(w, ws.hWin, ldh, ws.hZ, ldh, sp.data() + wb, sub, thres, carried, &und);
             window_to_device(L, wb, w, ldh);
@@ -787,6 +792,7 @@ struct Driver {
         }
         if (carried > 0) { top = bottom; carried = 0; }
         int const ns = top, nd = nw - ns;
+        double const tl2 = wall(); prof_laed[1] += tl2 - tl1;
         // shifts: the eigenvalues of the undeflated leading part (all of them if it is tiny)
         {
             std::vector<double> dg(nw), sup(nw, 0.0);
@@ -831,6 +837,7 @@ struct Driver {
             SN_HIP_CHECK(hipStreamSynchronize(ts));
             st.gemm_flops += 2.0 * ns * ns * ((double)nd + nw);
         }
+        double const tl3 = wall(); prof_laed[2] += tl3 - tl2;
         // (5) window back into H, coupling entry, off-window updates of H and Q
         copy_matrix(ts, nw, nw, L.dT, ld, H + (size_t)kw * ldH + kw, ldH);
         if (sub != 0.0)
@@ -841,6 +848,7 @@ struct Driver {
         int const ldh = host_ld(nw);
         SN_HIP_CHECK(hipMemcpy2DAsync(ws.hWin, (size_t)ldh * 8, L.dT, (size_t)ld * 8, (size_t)nw * 8, nw,
             hipMemcpyDeviceToHost, ts));
+        prof_laed[3] += wall() - tl3;
         return res;
     }
 
@@ -1247,7 +1255,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // short anyway, so the multiplicity grows with the size: 2 below n = 4000, 4 below 12000, 8
     // above.  SN_SCHUR_REUSE=k overrides.
     int const reuse_env = tuning().schur_reuse;
-    int const reuse = reuse_env ? reuse_env : (n < 4000 ? 2 : (n < 12000 ? 4 : 8));
+    // (a conf with many shifts -- the reference's 0.06 n -- fills the sweep by itself: the multiplicity is
+    // capped so that a sweep carries ~450 bulges, what 8 x 53 give at the default sizes)
+    int const reuse_n = n < 4000 ? 2 : (n < 12000 ? 4 : 8);
+    int const reuse = reuse_env ? reuse_env : std::max(1, std::min(reuse_n, 450 / std::max(1, ns_conf / 2)));
     ws.ensure(n, wmax, divceil(reuse * (ns_conf / 2), NB_MAX) + 2);
     ws.guard_row = 0;
     Driver d{s, n, dH, ldH, dQ, ldQ, ws, SchurStats{}};
@@ -1489,6 +1500,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     if (tuning().schur_profile && d.prof_agg_flushes > 0)
         fprintf(stderr, "[schur] aggregated flushes %ld, tiles %ld, ~launches %ld: plan %.3f s, descriptors %.3f s, launches %.3f s\n",
             d.prof_agg_flushes, d.prof_agg_tiles, d.prof_agg_launches, d.prof_agg_plan, d.prof_agg_desc, d.prof_agg_launch);
+    if (tuning().schur_profile && d.prof_laed_calls > 0)
+        fprintf(stderr, "[schur] blocked AED: %d calls, %d deflation windows: Schur form of the window %.3f s, deflation / reordering %.3f s, "
+            "re-Hessenberg %.3f s, write-back and updates (issue) %.3f s\n", d.prof_laed_calls, d.prof_laed_windows,
+            d.prof_laed[0], d.prof_laed[1], d.prof_laed[2], d.prof_laed[3]);
     if (tuning().schur_profile)
         fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d; n %d sweeps %d aeds %d chain passes %ld\n",
             d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves,
