@@ -1572,7 +1572,8 @@ int sn_internal_agg_apply(int mode, int ilo, int ihi, int ws_, int nbc, int chai
 // steps t_first..t_last of a sweep.  out[3 i .. 3 i + 2] = (tile, wavefront, window start) of the i-th
 // factor in issue order; returns the number of factors, < 0 if the geometry is not aggregated.
 extern "C" __attribute__((visibility("default")))
-int sn_internal_agg_plan(int ilo, int ihi, int ws_, int nbc, int chains, int t_first, int t_last, int *out, int cap)
+int sn_internal_agg_plan(int ilo, int ihi, int ws_, int nbc, int chains, int t_first, int t_last, int *out, int cap,
+    int lu, int lc)
 {
     using namespace sn;
     int const adv = ws_ - 1 - 3 * nbc;
@@ -1596,7 +1597,9 @@ int sn_internal_agg_plan(int ilo, int ihi, int ws_, int nbc, int chains, int t_f
     AggPlan plan;
     // the "address" of a factor is its issue index: the plan hands it back in AggFactor::U
     double const *base = nullptr;
-    agg_plan(steps, [&](size_t i) { return base + uoff[i] * 96 * 96; }, [&](size_t) { return 0; }, plan);
+    if (lu * lc > AGG_MAXF) return -3;
+    agg_plan(steps, [&](size_t i) { return base + uoff[i] * 96 * 96; }, [&](size_t) { return 0; }, plan,
+        lu > 0 ? lu : AGG_LU, lc > 0 ? lc : AGG_LC);
     for (size_t v = 0; v + 1 < plan.wave_begin.size(); v++)
         for (int k = plan.wave_begin[v]; k < plan.wave_begin[v + 1]; k++) {
             AggTile const &t = plan.tiles[k];

@@ -354,7 +354,8 @@ struct AggPlan {
 // ubuf(i): device address of the factors of step i (ntasks blocks of 96 x 96); rsplit(i): lazy rows
 // [0, rsplit(i)) of step i (non-decreasing).  G buffers are assigned by the caller.
 template <typename UbufFn, typename RsFn>
-inline void agg_plan(std::vector<SweepStep> const &steps, UbufFn ubuf, RsFn rsplit, AggPlan &plan)
+inline void agg_plan(std::vector<SweepStep> const &steps, UbufFn ubuf, RsFn rsplit, AggPlan &plan,
+    int LU = AGG_LU, int LC = AGG_LC)
 {
     plan.tiles.clear(); plan.wave_begin.clear(); plan.flops_q_per_row = 0.0;
     if (steps.empty()) return;
@@ -366,8 +367,8 @@ inline void agg_plan(std::vector<SweepStep> const &steps, UbufFn ubuf, RsFn rspl
     int ub_min = 1 << 30, ub_max = -(1 << 30), cb_max = 0;
     for (SweepStep const &st : steps)
         for (int k = 0; k < st.ntasks; k++) {
-            int const c = st.cmin + k, ub = floordiv(st.t - skew * c, AGG_LU);
-            ub_min = std::min(ub_min, ub); ub_max = std::max(ub_max, ub); cb_max = std::max(cb_max, c / AGG_LC);
+            int const c = st.cmin + k, ub = floordiv(st.t - skew * c, LU);
+            ub_min = std::min(ub_min, ub); ub_max = std::max(ub_max, ub); cb_max = std::max(cb_max, c / LC);
         }
     int const nub = ub_max - ub_min + 1, ncb = cb_max + 1;
     std::vector<int> slot((size_t)nub * ncb, -1);
@@ -377,7 +378,7 @@ inline void agg_plan(std::vector<SweepStep> const &steps, UbufFn ubuf, RsFn rspl
         SweepStep const &st = steps[i];
         for (int k = 0; k < st.ntasks; k++) {
             ChaseTask const tk = make_task(st, k);
-            int const c = st.cmin + k, ub = floordiv(st.t - skew * c, AGG_LU) - ub_min, cb = c / AGG_LC;
+            int const c = st.cmin + k, ub = floordiv(st.t - skew * c, LU) - ub_min, cb = c / LC;
             int &s = slot[(size_t)ub * ncb + cb];
             if (s < 0) {
                 s = (int)raw.size();
