@@ -30,3 +30,21 @@ for k, v in sorted(tot.items(), key=lambda x: -x[1])[:12]:
 # the ten longest gaps with what followed
 order = np.argsort(-per)[:8]
 print("longest gaps (ms):", " ".join(f"{per[i] / 1e3:.1f}" for i in order))
+# GPU occupancy over the leg: union of all kernel intervals, tail after the last chase launch, idle gaps
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows
+            if int(r["End_Timestamp"]) >= t0 and int(r["Start_Timestamp"]) <= t1 + 2e9 and "hess_" not in r["Kernel_Name"])
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+gaps_idle = []
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        busy += cur_e - cur_s; gaps_idle.append(s_ - cur_e); cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+busy += cur_e - cur_s
+end_all = max(e for _, e in iv)
+print(f"leg span (first chase start .. last kernel end) {(end_all - t0) / 1e9:.3f} s; some kernel running {busy / 1e9:.3f} s; "
+      f"tail after the last chase kernel {(end_all - t1) / 1e9:.3f} s; idle gaps > 50 us: {sum(1 for g in gaps_idle if g > 5e4)} "
+      f"sum {sum(g for g in gaps_idle if g > 5e4) / 1e9:.3f} s")
+# concurrency: sum of kernel durations / busy time
+tot_dur = sum(e - s for s, e in iv)
+print(f"sum of kernel durations {tot_dur / 1e9:.3f} s -> average concurrency {tot_dur / busy:.2f}")

@@ -557,6 +557,15 @@ struct HessWorkspace {
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest
             // the latency-critical panel chain outranks the bulk GEMM updates
             SN_HIP_CHECK(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, hi));
+            if (tuning().hess_side_cus > 0) {
+                // experiment: the delayed updates confined to the first `hess_side_cus` CUs
+                hipDeviceProp_t prop; int dev = 0;
+                SN_HIP_CHECK(hipGetDevice(&dev)); SN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                int const ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+                std::vector<uint32_t> mask(words, 0u);
+                for (int i = 0; i < std::min(ncu, tuning().hess_side_cus); i++) mask[i / 32] |= 1u << (i % 32);
+                SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&side, words, mask.data()));
+            } else
             SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
             SN_HIP_CHECK(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
             for (int k = 0; k < 2; k++) {

@@ -11,6 +11,7 @@ struct Tuning {
     int hess_max_split = 32;        // SN_HESS_MAXSPLIT
     int hess_max_panels = 1 << 30;  // SN_HESS_MAX_PANELS: stop after k panels (PMC runs); the result is then partial
     long hess_cache_mb = 256;       // SN_HESS_CACHE_MB: trailing matrices below this size are read with temporal loads
+    int hess_side_cus = 0;          // SN_HESS_SIDE_CUS: CU mask of the side stream (0 = none)
     bool hess_noside = false;       // SN_HESS_NOSIDE: delayed updates on the critical stream
     // Schur
     bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
