@@ -48,3 +48,30 @@ print(f"leg span (first chase start .. last kernel end) {(end_all - t0) / 1e9:.3
 # concurrency: sum of kernel durations / busy time
 tot_dur = sum(e - s for s, e in iv)
 print(f"sum of kernel durations {tot_dur / 1e9:.3f} s -> average concurrency {tot_dur / busy:.2f}")
+# what runs inside one of the long gaps between chase launches (the 5th longest: a mid-run cycle)
+gi = int(np.argsort(-per)[4])
+g0, g1 = st[gi] * 1e3, st[gi + 1] * 1e3
+print(f"gap {per[gi] / 1e3:.1f} ms: kernels by name inside it (count, total ms, first start ms, last end ms after the gap's first chase)")
+agg = {}
+for r in rows:
+    s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if e_ < g0 or s_ > g1: continue
+    k = r["Kernel_Name"].split("(")[0][-40:]
+    a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+    a[0] += 1; a[1] += (e_ - s_) / 1e6; a[2] = min(a[2], (s_ - g0) / 1e6); a[3] = max(a[3], (e_ - g0) / 1e6)
+for k, a in sorted(agg.items(), key=lambda x: x[1][2]):
+    print(f"  {k:42s} n={a[0]:5d} total {a[1]:8.2f} ms  first {a[2]:8.2f}  last end {a[3]:8.2f}")
+# the scan kernels mark the host's AED iterations: their start times inside the gap
+sc = sorted((int(r["Start_Timestamp"]) - g0) / 1e6 for r in rows if "scan_subdiag" in r["Kernel_Name"] and g0 <= int(r["Start_Timestamp"]) <= g1)
+print("  scan kernel starts (ms):", " ".join(f"{x:.1f}" for x in sc))
+# bursts of chase launches (period <= 600 us) and the scan kernels (host AED iterations) between them
+scan_t = np.array(sorted(int(r["Start_Timestamp"]) for r in rows if "scan_subdiag" in r["Kernel_Name"]), dtype=np.float64) / 1e3
+bursts = []
+b0 = 0
+for i in range(len(per) + 1):
+    if i == len(per) or per[i] > 600:
+        bursts.append((st[b0], en[i], i - b0 + 1)); b0 = i + 1
+print("bursts of chase launches: start ms, length ms, launches | scans during the burst | idle ms and scans before the next burst")
+for k, (a, b, cnt) in enumerate(bursts[:60]):
+    nxt = bursts[k + 1][0] if k + 1 < len(bursts) else b
+    print(f"  {(a - st[0]) / 1e3:9.1f} {(b - a) / 1e3:7.1f} {cnt:5d} | {int(np.sum((scan_t >= a) & (scan_t <= b))):3d} | {(nxt - b) / 1e3:7.1f} {int(np.sum((scan_t > b) & (scan_t < nxt))):3d}")

@@ -858,6 +858,8 @@ struct Driver {
     // critical path of the sweep so that they execute while the host reduces the AED windows
     // that follow, instead of competing with the sweep for the CUs.
     double prof_scan_wait = 0, prof_dl_wait = 0, prof_issue = 0; int prof_guard_moves = 0;
+    double prof_scan_wait_la = 0; int prof_la_cycles = 0, prof_la_done_at_chain_end = 0; double prof_la_chain_s = 0;
+    double prof_la_t0 = 0; hipEvent_t prof_la_ev = nullptr;
     struct LazyItem { SweepStep step; int ev; int row_split; };
     std::vector<LazyItem> lazy;
     // descriptors for `count` tiles from the pinned ring (contiguous); the blocks they cover were
@@ -1314,6 +1316,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         return nsh * m;
     };
     auto finish_lookahead = [&](int ihi_now) {
+        if (tuning().schur_profile && d.prof_la_ev && d.prof_la_t0 > 0) {
+            d.prof_la_chain_s += wall() - d.prof_la_t0; d.prof_la_t0 = 0;
+            if (hipEventQuery(d.prof_la_ev) == hipSuccess) d.prof_la_done_at_chain_end++;
+        }
         // phase B: the AED stream is done with the bottom of the block, the lazy H updates issued
         // so far (phase A, AED) are waited for -- rows near the guard row become timely again
         SN_HIP_CHECK(hipEventRecord(ws.aed_mark, ws.aed));
@@ -1344,6 +1350,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
                 hipMemcpyDeviceToHost, d.ts));
             SN_HIP_CHECK(hipStreamSynchronize(d.ts));
             d.st.wait_s += wall() - tw; d.prof_scan_wait += wall() - tw;
+            if (la) d.prof_scan_wait_la += wall() - tw;
         }
         int ilo = ihi - 1;
         while (ilo > scan_lo && ws.hSub[ilo - 1] != 0.0) ilo--;
@@ -1389,6 +1396,11 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
                 d.sweep_issue(r1);
                 d.flush_lazy(r1);               // ... run while the host is busy with the AEDs
                 d.prof_issue += wall() - t_issue;
+                if (tuning().schur_profile) {   // is the head of the sweep through when the AED chain ends?
+                    if (!d.prof_la_ev) SN_HIP_CHECK(hipEventCreateWithFlags(&d.prof_la_ev, hipEventDisableTiming));
+                    SN_HIP_CHECK(hipEventRecord(d.prof_la_ev, s));
+                    d.prof_la_t0 = wall(); d.prof_la_cycles++;
+                }
                 d.ts = ws.aed;
                 iter++;
             }
@@ -1504,6 +1516,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         fprintf(stderr, "[schur] blocked AED: %d calls, %d deflation windows: Schur form of the window %.3f s, deflation / reordering %.3f s, "
             "re-Hessenberg %.3f s, write-back and updates (issue) %.3f s\n", d.prof_laed_calls, d.prof_laed_windows,
             d.prof_laed[0], d.prof_laed[1], d.prof_laed[2], d.prof_laed[3]);
+    if (tuning().schur_profile)
+        fprintf(stderr, "[schur] look-ahead: %d sweeps started ahead of their AED chain; the head was through when the chain ended in %d; "
+            "host time from the head's issue to the chain's end %.3f s; scan-sync wait while a head is in flight %.3f s\n",
+            d.prof_la_cycles, d.prof_la_done_at_chain_end, d.prof_la_chain_s, d.prof_scan_wait_la);
     if (tuning().schur_profile)
         fprintf(stderr, "[schur] total %.3f s: aed_host %.3f, scan-sync wait %.3f, download-sync wait %.3f, sweep issue %.3f, guard moves %d; n %d sweeps %d aeds %d chain passes %ld\n",
             d.st.total_ms * 1e-3, d.st.aed_host_s, d.prof_scan_wait, d.prof_dl_wait, d.prof_issue, d.prof_guard_moves,
