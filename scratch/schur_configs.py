@@ -2,8 +2,11 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import starneig_amd as S
+if os.environ.get("SN_USE_TEST_LIB"):       # the hooks build as the product (SN_AED_DUMP lives there)
+    import starneig_amd.lib as _l
+    _l.LIB_PATH = _l.TEST_LIB_PATH
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
-S.node_init(1,1,S.NO_MESSAGES)
+S.node_init(int(os.environ.get("SN_CORES", "1")),1,S.NO_MESSAGES)
 n = int(sys.argv[1])
 tA0 = S.device_matrix(n); S.lcg_fill_device(tA0, n, n)
 tH = tA0.clone(); tQ0 = S.device_matrix(n); S.set_matrix_device(tQ0, n, n, 0.0, 1.0)

@@ -15,6 +15,7 @@ namespace {
 
 struct RcclApi {
     void *handle = nullptr;
+    bool failed = false;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -26,9 +27,15 @@ struct RcclApi {
     bool load()
     {
         if (handle) return true;
-        handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!handle) handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!handle) return false;
+        if (failed) return false;
+        // the copy already in the process (torch's, under its soname) before any other on the path:
+        // two RCCL runtimes in one process is the thing to avoid
+        char const *names[] = {"librccl.so.1", "librccl.so"};
+        for (char const *name : names)
+            if (!handle) handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        for (char const *name : names)
+            if (!handle) handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!handle) { failed = true; return false; }
         auto sym = [&](const char *name) { return dlsym(handle, name); };
         GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
@@ -36,7 +43,15 @@ struct RcclApi {
         AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
         Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !Broadcast) { handle = nullptr; return false; }
+        auto version = (ncclResult_t (*)(int *))sym("ncclGetVersion");
+        int v = 0;
+        bool ok = GetUniqueId && CommInitRank && CommDestroy && AllReduce && Broadcast && version &&
+                  version(&v) == ncclSuccess && v / 10000 == NCCL_VERSION_CODE / 10000;
+        if (!ok) {
+            if (version && v) fprintf(stderr, "[starneig-amd] RCCL %d at run time, built against %d: not used\n", v, NCCL_VERSION_CODE);
+            dlclose(handle); handle = nullptr; failed = true;
+            return false;
+        }
         return true;
     }
 };

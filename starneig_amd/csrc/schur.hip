@@ -1212,18 +1212,26 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     int const min_val = lapack_min_shifts(n);
     int nw_default = (int)std::max(min_val / 0.7, 0.08 * n);
     int ns_default = (int)std::max((double)min_val, 0.06 * n);
-    // the AED window is reduced on the host in this revision (O(w^3) scalar work per call) and
-    // every shift pair drives several bulges (see `reuse` below): the measured optimum at
-    // n = 20000 is 160 / 106 (4.6 s; 5.0 s at 192 / 128, 6.0 s at 224 / 150, 13 s at 256 / 170
-    // where the host kernel falls out of cache); explicit conf values are honoured up to 1024
-    nw_default = std::min(nw_default, 160);
-    ns_default = std::min(ns_default, 106);
+    // The AED window is reduced on the host (O(w^3) work per call, one chain of small reflectors)
+    // and every shift pair drives several bulges (see `reuse` below), so the best window is much
+    // smaller than the reference's 0.08 n: a larger one saves sweeps and costs host time.  With
+    // the helper team of the window kernel (schur_host_team.h) the optimum at n = 20000 is flat
+    // between 224 / 140 and 288 / 180 (1.82-1.92 s; 2.3 s at 160 / 106), without it around
+    // 192 / 128 - 208 / 128 (2.15 s); explicit conf values are honoured up to 1024.
+    int const helpers = level == 0 ? (tuning().schur_helpers >= 0 ? std::min(tuning().schur_helpers, prm.host_threads - 1)
+                                                                 : (prm.host_threads >= 6 ? 5 : 0)) : 0;
+    nw_default = std::min(nw_default, helpers >= 2 ? 256 : 192);
+    ns_default = std::min(ns_default, helpers >= 2 ? 160 : 128);
     // AED windows above the hard limit (process_args.c:372-398, default 300) are reduced by the
     // blocked device path (Driver::large_aed, row S5), the others by the sequential host kernel;
     // the private window of a blocked AED (level 1) always takes the small defaults
     int const hard_limit = prm.aed_parallel_hard_limit > 0 ? prm.aed_parallel_hard_limit : 300;
     int nw_conf = prm.aed_window_size > 0 ? prm.aed_window_size : nw_default;
     if (level > 0) nw_conf = std::min(nw_conf, std::min(hard_limit, 300));
+    // a replica that carries a row block of Q (q_rows < n: the sharded Schur leg) must stay
+    // bit-identical to its peers, and the blocked device AED is not (atomics in its
+    // re-Hessenberg step): such a call keeps its windows on the sequential host kernel
+    if (q_rows >= 0 && q_rows < n) nw_conf = std::min(nw_conf, hard_limit);
     nw_conf = std::min(nw_conf, std::max(4, n));
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : ns_default;
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
@@ -1239,9 +1247,9 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // serial loops already run at the speed of the pipelined ones on that CPU) and so is the leg.
     struct HelperSession {
         bool on;
-        explicit HelperSession(bool o) : on(o) { if (on) host::helper_session(true); }
+        explicit HelperSession(int count) : on(count >= 2) { if (on) host::helper_session(true, count); }
         ~HelperSession() { if (on) host::helper_session(false); }
-    } helper_session(level == 0 && prm.host_threads >= 3 && tuning().schur_helpers);
+    } helper_session(helpers);
 
     SchurWorkspace &ws = g_sws[level];
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});

@@ -11,7 +11,7 @@ struct AedResult {
 
 void lanv2(double &a, double &b, double &c, double &d,
     double &rt1r, double &rt1i, double &rt2r, double &rt2i, double &cs, double &sn);
-void helper_session(bool on);
+void helper_session(bool on, int count = 5);   // `count` helper threads for the window kernels (schur_host_team.h)
 int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi);
 int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to);
 int deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,

@@ -22,191 +22,25 @@
 #include <mutex>
 #include <condition_variable>
 #include <immintrin.h>
+#include "schur_host_team.h"
 
 namespace sn { namespace host {
 
-// ---- helper threads of the sequential window kernels ------------------------------------------
-// The double-shift QR sweep of small_schur is a serial chain of 3x3 reflectors; only the part of
-// each reflector's application that the NEXT reflector depends on has to stay on that chain: the
-// rows inside the active block from the left, the columns from the right.  The two other parts
-// -- the accumulation into Z, and the left update of the columns right of the active block (the
-// already converged part of T) -- touch data the chain never reads again, so they are handed to
-// two helper threads through single-producer rings and applied there in order.  Every entry sees
-// the same operations in the same order as in the serial loop: the results are bit-identical.
-// The helpers exist only while a session is open (one Schur reduction) and `cores` >= 3.
+// ---- helper threads of the sequential window kernels (schur_host_team.h) -----------------------
 namespace {
-
-// Row operations on a column-major matrix touch 2-3 adjacent entries of every column: the loops
-// cannot vectorise, and without help the compiler serialises them (a store to column j might
-// alias the load of column j+1 for all it knows).  Four columns are loaded before any is stored.
-static inline void rows3_reflect(double *T, int ldt, int k2, int j0, int j1, double v2, double v3, double t1)
-{
-    double const t2 = t1 * v2, t3 = t1 * v3;
-    int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        double *p0 = T + (size_t)j * ldt + k2, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
-        double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
-        double c0 = p2[0], c1 = p2[1], c2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
-        double sa = a0 + v2 * a1 + v3 * a2, sb = b0 + v2 * b1 + v3 * b2;
-        double sc = c0 + v2 * c1 + v3 * c2, sd = d0 + v2 * d1 + v3 * d2;
-        p0[0] = a0 - sa * t1; p0[1] = a1 - sa * t2; p0[2] = a2 - sa * t3;
-        p1[0] = b0 - sb * t1; p1[1] = b1 - sb * t2; p1[2] = b2 - sb * t3;
-        p2[0] = c0 - sc * t1; p2[1] = c1 - sc * t2; p2[2] = c2 - sc * t3;
-        p3[0] = d0 - sd * t1; p3[1] = d1 - sd * t2; p3[2] = d2 - sd * t3;
-    }
-    for (; j < j1; j++) {
-        double *p = T + (size_t)j * ldt + k2;
-        double a0 = p[0], a1 = p[1], a2 = p[2];
-        double sa = a0 + v2 * a1 + v3 * a2;
-        p[0] = a0 - sa * t1; p[1] = a1 - sa * t2; p[2] = a2 - sa * t3;
-    }
-}
-static inline void rows2_reflect(double *T, int ldt, int k2, int j0, int j1, double v2, double t1)
-{
-    double const t2 = t1 * v2;
-    int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        double *p0 = T + (size_t)j * ldt + k2, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
-        double a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
-        double sa = a0 + v2 * a1, sb = b0 + v2 * b1, sc = c0 + v2 * c1, sd = d0 + v2 * d1;
-        p0[0] = a0 - sa * t1; p0[1] = a1 - sa * t2; p1[0] = b0 - sb * t1; p1[1] = b1 - sb * t2;
-        p2[0] = c0 - sc * t1; p2[1] = c1 - sc * t2; p3[0] = d0 - sd * t1; p3[1] = d1 - sd * t2;
-    }
-    for (; j < j1; j++) {
-        double *p = T + (size_t)j * ldt + k2;
-        double a0 = p[0], a1 = p[1], sa = a0 + v2 * a1;
-        p[0] = a0 - sa * t1; p[1] = a1 - sa * t2;
-    }
-}
-// rows r1, r2 (any distance) over columns [c0, c1): x' = cs x + sn y, y' = cs y - sn x
-static inline void rows_rotate(double *T, int ldt, int r1, int r2, int c0, int c1, double cs, double sn)
-{
-    int j = c0;
-    for (; j + 4 <= c1; j += 4) {
-        double *p0 = T + (size_t)j * ldt, *p1 = p0 + ldt, *p2 = p1 + ldt, *p3 = p2 + ldt;
-        double x0 = p0[r1], y0 = p0[r2], x1 = p1[r1], y1 = p1[r2], x2 = p2[r1], y2 = p2[r2], x3 = p3[r1], y3 = p3[r2];
-        p0[r1] = cs * x0 + sn * y0; p0[r2] = cs * y0 - sn * x0;
-        p1[r1] = cs * x1 + sn * y1; p1[r2] = cs * y1 - sn * x1;
-        p2[r1] = cs * x2 + sn * y2; p2[r2] = cs * y2 - sn * x2;
-        p3[r1] = cs * x3 + sn * y3; p3[r2] = cs * y3 - sn * x3;
-    }
-    for (; j < c1; j++) {
-        double *p = T + (size_t)j * ldt;
-        double x = p[r1], y = p[r2];
-        p[r1] = cs * x + sn * y; p[r2] = cs * y - sn * x;
-    }
-}
-
-struct ReflOp { int k2, nr, from, kind; double a, b, c; };   // kind 0: reflector (v2, v3, t1); 1: rotation (cs, sn)
-
-struct OpRing {
-    static constexpr unsigned CAP = 2048;
-    ReflOp ops[CAP];
-    alignas(64) std::atomic<unsigned> head{0};      // next slot to write (producer)
-    alignas(64) std::atomic<unsigned> tail{0};      // next slot to read (consumer)
-    void push(ReflOp const &op) {
-        unsigned h = head.load(std::memory_order_relaxed);
-        while (h - tail.load(std::memory_order_acquire) >= CAP) _mm_pause();
-        ops[h % CAP] = op;
-        head.store(h + 1, std::memory_order_release);
-    }
-    void wait_empty() { while (tail.load(std::memory_order_acquire) != head.load(std::memory_order_relaxed)) _mm_pause(); }
-};
-
-struct Job { double *M = nullptr; int ld = 0, n = 0; };
-
-struct Helpers {
-    OpRing ring[2];                 // 0: Z accumulation, 1: left updates of the converged columns of T
-    Job job[2];
-    std::thread th[2];
-    std::mutex mu;
-    std::condition_variable cv;
-    bool session = false, quit = false, started = false;
-
-    // Z(:, k2 : k2+nr) <- . G  (all rows): the same loops as in small_schur
-    __attribute__((noinline)) static void apply_z(Job const &jb, ReflOp const &op) {
-        double *Z = jb.M; int const ldz = jb.ld, n = jb.n;
-        if (op.kind == 1) {
-            double *__restrict__ a = &Z[(size_t)op.k2 * ldz], *__restrict__ b = &Z[(size_t)(op.k2 + 1) * ldz];
-            for (int i = 0; i < n; i++) { double x = a[i], y = b[i]; a[i] = op.a * x + op.b * y; b[i] = op.a * y - op.b * x; }
-            return;
-        }
-        double const v2 = op.a, v3 = op.b, t1 = op.c, t2 = t1 * v2, t3 = t1 * v3;
-        double *__restrict__ z0 = &Z[(size_t)op.k2 * ldz], *__restrict__ z1 = &Z[(size_t)(op.k2 + 1) * ldz];
-        if (op.nr == 3) {
-            double *__restrict__ z2 = &Z[(size_t)(op.k2 + 2) * ldz];
-            for (int j = 0; j < n; j++) {
-                double sum = z0[j] + v2 * z1[j] + v3 * z2[j];
-                z0[j] -= sum * t1; z1[j] -= sum * t2; z2[j] -= sum * t3;
-            }
-        } else {
-            for (int j = 0; j < n; j++) {
-                double sum = z0[j] + v2 * z1[j];
-                z0[j] -= sum * t1; z1[j] -= sum * t2;
-            }
-        }
-    }
-    // T(k2 : k2+nr, from : n) <- G^T .   (columns right of the active block)
-    __attribute__((noinline)) static void apply_left(Job const &jb, ReflOp const &op) {
-        if (op.kind == 1) rows_rotate(jb.M, jb.ld, op.k2, op.k2 + 1, op.from, jb.n, op.a, op.b);
-        else if (op.nr == 3) rows3_reflect(jb.M, jb.ld, op.k2, op.from, jb.n, op.a, op.b, op.c);
-        else rows2_reflect(jb.M, jb.ld, op.k2, op.from, jb.n, op.a, op.c);
-    }
-    void run(int which) {
-        OpRing &r = ring[which];
-        for (;;) {
-            {   // parked between sessions
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return session || quit; });
-                if (quit) return;
-            }
-            unsigned idle = 0;
-            for (;;) {
-                unsigned t = r.tail.load(std::memory_order_relaxed);
-                if (t != r.head.load(std::memory_order_acquire)) {
-                    ReflOp const op = r.ops[t % OpRing::CAP];
-                    if (which == 0) apply_z(job[0], op); else apply_left(job[1], op);
-                    r.tail.store(t + 1, std::memory_order_release);
-                    idle = 0;
-                } else {
-                    _mm_pause();
-                    if (++idle > 4096) {
-                        idle = 0;
-                        std::unique_lock<std::mutex> lk(mu);
-                        if (!session) break;
-                    }
-                }
-            }
-        }
-    }
-    void open() {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!started) { th[0] = std::thread([this] { run(0); }); th[1] = std::thread([this] { run(1); }); started = true; }
-        session = true;
-        cv.notify_all();
-    }
-    void close() { std::lock_guard<std::mutex> lk(mu); session = false; }
-    ~Helpers() {
-        if (!started) return;
-        { std::lock_guard<std::mutex> lk(mu); quit = true; session = false; }
-        cv.notify_all();
-        for (auto &t : th) if (t.joinable()) t.join();
-    }
-};
-
-Helpers &helpers() { static Helpers h; return h; }
+Team &team() { static Team t; return t; }
 bool g_helpers_on = false;
-
 } // namespace
 
 // Opens / closes a helper session (schur_device brackets a reduction with it when the node has
-// at least 3 cores; tests switch it on to compare against the serial kernels bit for bit).
-void helper_session(bool on)
+// the cores; tests switch it on to compare against the serial kernels bit for bit).
+void helper_session(bool on, int count)
 {
     if (on == g_helpers_on) return;
-    if (on) helpers().open(); else helpers().close();
+    if (on) team().open(count); else team().close();
     g_helpers_on = on;
 }
+static inline Team *team_for(int n) { return (g_helpers_on && n >= 48) ? &team() : nullptr; }
 
 static inline double sign(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::fabs(a); }
 
@@ -263,11 +97,23 @@ void lanv2(double &a, double &b, double &c, double &d,
 // Householder vector for x (length n, n <= 4): x <- [beta; v(1:)], returns tau (v(0) = 1).
 static double house(int n, double *x)
 {
-    double xnorm = 0.0;
-    for (int i = 1; i < n; i++) xnorm = std::hypot(xnorm, x[i]);
+    // the norms by plain sums of squares when every entry is far from the ends of the exponent range
+    // (always, in practice), by hypot otherwise: hypot is several times the cost of the whole 3x3 case
+    double big = 0.0, small = DBL_MAX, ssq = 0.0;
+    for (int i = 1; i < n; i++) { double a = std::fabs(x[i]); big = std::max(big, a); if (a != 0.0) small = std::min(small, a); ssq += a * a; }
+    if (big == 0.0) return 0.0;
+    double const a0 = std::fabs(x[0]);
+    big = std::max(big, a0); if (a0 != 0.0) small = std::min(small, a0);
+    double xnorm, nrm;
+    if (big < 1e140 && small > 1e-140) { xnorm = std::sqrt(ssq); nrm = std::sqrt(ssq + a0 * a0); }
+    else {
+        xnorm = 0.0;
+        for (int i = 1; i < n; i++) xnorm = std::hypot(xnorm, x[i]);
+        nrm = std::hypot(x[0], xnorm);
+    }
     if (xnorm == 0.0) return 0.0;
     double alpha = x[0];
-    double beta = -sign(std::hypot(alpha, xnorm), alpha);
+    double beta = -sign(nrm, alpha);
     double tau = (beta - alpha) / beta, s = 1.0 / (alpha - beta);
     for (int i = 1; i < n; i++) x[i] *= s;
     x[0] = beta;
@@ -277,38 +123,17 @@ static double house(int n, double *x)
 #define T_(i, j) T[(size_t)(j) * ldt + (i)]
 #define Z_(i, j) Z[(size_t)(j) * ldz + (i)]
 
-// rotate rows r1, r2 of T over columns [c0, c1): x' = cs x + sn y, y' = cs y - sn x
-static void rot_rows(double *T, int ldt, int r1, int r2, int c0, int c1, double cs, double sn)
-{
-    rows_rotate(T, ldt, r1, r2, c0, c1, cs, sn);
-}
-static void rot_cols(double *T, int ldt, int c1, int c2, int r0, int r1, double cs, double sn)
-{
-    double *__restrict__ a = &T_(0, c1), *__restrict__ b = &T_(0, c2);      // distinct columns: vectorises
-    for (int i = r0; i < r1; i++) {
-        double x = a[i], y = b[i];
-        a[i] = cs * x + sn * y; b[i] = cs * y - sn * x;
-    }
-}
-
 // ---- double-shift QR on a small Hessenberg matrix (LAPACK dlahqr, full Schur form) ---
-int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi)
+// With a team (ap.team): Z, the columns right of the active block and the rows above it are the
+// helpers' (see schur_host_team.h); on return T is whole again, Z may still be in flight.
+static int small_schur(Applier &ap, double *wr, double *wi)
 {
+    int const n = ap.n, ldt = ap.ldt; double *const T = ap.T;
     const double ulp = DBL_EPSILON, safmin = DBL_MIN;
     const double smlnum = safmin * ((double)n / ulp);
     const int itmax = 30 * std::max(10, n), kexsh = 10;
     if (n == 0) return 0;
     for (int j = 0; j + 2 < n; j++) { T_(j + 2, j) = 0.0; if (j + 3 < n) T_(j + 3, j) = 0.0; }
-    // with helpers: Z and the converged columns of T are updated by two other threads (see above)
-    bool const piped = g_helpers_on && n >= 48;
-    OpRing *qz = nullptr, *ql = nullptr;
-    if (piped) {
-        Helpers &h = helpers();
-        h.job[0] = Job{Z, ldz, n}; h.job[1] = Job{T, ldt, n};
-        qz = &h.ring[0]; ql = &h.ring[1];
-    }
-    struct Drain { OpRing *a, *b; ~Drain() { if (a) a->wait_empty(); if (b) b->wait_empty(); } } drain{qz, ql};
-
     int i = n - 1;
     while (i >= 0) {
         int l = 0;
@@ -384,58 +209,48 @@ int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, doubl
                 double t1 = house(nr, v);
                 if (k2 > m) { T_(k2, k2 - 1) = v[0]; T_(k2 + 1, k2 - 1) = 0.0; if (k2 < i - 1) T_(k2 + 2, k2 - 1) = 0.0; }
                 else if (m > l) T_(k2, k2 - 1) *= (1.0 - t1);
-                double v2 = v[1], t2 = t1 * v2;
-                // the parts the chain never reads again: on the helper threads, or (the SAME code) here
-                {
-                    ReflOp const op{k2, nr, i + 1, 0, v2, nr == 3 ? v[2] : 0.0, t1};
-                    if (piped) { ql->push(op); qz->push(op); }
-                    else { Helpers::apply_left(Job{T, ldt, n}, op); Helpers::apply_z(Job{Z, ldz, n}, op); }
-                }
-                int const jend = i + 1;                     // left update here: the active block only
-                if (nr == 3) {
-                    double v3 = v[2], t3 = t1 * v3;
-                    rows3_reflect(T, ldt, k2, k2, jend, v2, v3, t1);
-                    int je = std::min(k2 + 3, i);
-                    {   // three distinct columns: restrict-qualified so that the loops vectorise
-                        double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1), *__restrict__ c2 = &T_(0, k2 + 2);
-                        for (int j = 0; j <= je; j++) {
-                            double sum = c0[j] + v2 * c1[j] + v3 * c2[j];
-                            c0[j] -= sum * t1; c1[j] -= sum * t2; c2[j] -= sum * t3;
-                        }
-                    }
-                } else {
-                    rows2_reflect(T, ldt, k2, k2, jend, v2, t1);
-                    double *__restrict__ c0 = &T_(0, k2), *__restrict__ c1 = &T_(0, k2 + 1);
-                    for (int j = 0; j <= i; j++) {
-                        double sum = c0[j] + v2 * c1[j];
-                        c0[j] -= sum * t1; c1[j] -= sum * t2;
-                    }
-                }
+                // the chain's share: the rows inside the active block from the left, all of the columns.
+                // (The rows above l are not read again either, but they become "columns right of the
+                // active block" of a later, higher block: T(r, c) would then be one helper's as a row
+                // above and another's as a column to the right, and the order between the two is lost.)
+                ap.emit(Op{k2, (short)nr, 0, i + 1, 0, v[1], nr == 3 ? v[2] : 0.0, 0.0, t1}, k2, std::min(k2 + 3, i) + 1);
             }
+            ap.publish();
         }
-        if (!done) return i + 1;
+        if (!done) { ap.whole_t(); return i + 1; }
         if (l == i) { wr[i] = T_(i, i); wi[i] = 0.0; }
         else {
             double cs, sn;
             lanv2(T_(i - 1, i - 1), T_(i - 1, i), T_(i, i - 1), T_(i, i),
                 wr[i - 1], wi[i - 1], wr[i], wi[i], cs, sn);
-            {
-                ReflOp const op{i - 1, 2, i + 1, 1, cs, sn, 0.0};
-                if (piped) { ql->push(op); qz->push(op); }
-                else { Helpers::apply_left(Job{T, ldt, n}, op); Helpers::apply_z(Job{Z, ldz, n}, op); }
-            }
-            rot_cols(T, ldt, i - 1, i, 0, i - 1, cs, sn);
+            // the 2x2 block itself is standardised by lanv2: columns right of it, rows above it
+            ap.emit(Op{i - 1, 2, 1, i + 1, 0, cs, sn, 0.0, 0.0}, i + 1, i - 1);
         }
         i = l - 1;
     }
+    ap.whole_t();
     return 0;
+}
+
+int small_schur(int n, double *T, int ldt, double *Z, int ldz, double *wr, double *wi)
+{
+    if (n == 0) return 0;
+    Applier ap{T, ldt, Z, ldz, n, team_for(n)};
+    ap.w.resize(n);
+    if (ap.team) ap.team->begin(T, ldt, Z, ldz, n);
+    int const info = small_schur(ap, wr, wi);
+    ap.whole();
+    return info;
 }
 
 // ---- swapping adjacent diagonal blocks of a real Schur form (LAPACK dlaexc) ----------
 // Blocks T11 (n1 x n1) at j1 and T22 (n2 x n2) at j1+n1, n1,n2 in {1,2}.  Returns 0 if
 // swapped, 1 if the swap was rejected as too inaccurate (T, Z untouched).
-static int swap_blocks(int n, double *T, int ldt, double *Z, int ldz, int j1, int n1, int n2)
+// `hi`, `lo`: the caller reads nothing right of column hi or above row lo before the next wait on the
+// team (Applier::whole_t): those parts of the update, and Z, may be left to the helpers.
+static int swap_blocks(Applier &ap, int j1, int n1, int n2, int hi, int lo)
 {
+    int const n = ap.n, ldt = ap.ldt; double *const T = ap.T;
     if (n1 == 0 || n2 == 0) return 0;
     if (j1 + n1 >= n) return 0;
     const int nd = n1 + n2;
@@ -444,10 +259,8 @@ static int swap_blocks(int n, double *T, int ldt, double *Z, int ldz, int j1, in
         double f = T_(j1, j1 + 1), g = t22 - t11;
         double r = std::hypot(f, g), cs, sn;
         if (r == 0.0) { cs = 1.0; sn = 0.0; } else { cs = f / r; sn = g / r; }
-        rot_rows(T, ldt, j1, j1 + 1, j1 + 2, n, cs, sn);
-        rot_cols(T, ldt, j1, j1 + 1, 0, j1, cs, sn);
+        ap.emit(Op{j1, 2, 1, hi, lo, cs, sn, 0.0, 0.0}, j1 + 2, j1);
         T_(j1, j1) = t22; T_(j1 + 1, j1 + 1) = t11;
-        rot_cols(Z, ldz, j1, j1 + 1, 0, n, cs, sn);
         return 0;
     }
     // local copy D of the nd x nd diagonal block
@@ -534,34 +347,15 @@ static int swap_blocks(int n, double *T, int ldt, double *Z, int ldz, int j1, in
 
     // accept: apply to T and Z
     for (int k = 0; k < n2; k++) {
-        int len = nd - k, r0 = j1 + k;
-        for (int j = j1; j < n; j++) {
-            double s = 0.0;
-            for (int i = 0; i < len; i++) s += vv[k][i] * T_(r0 + i, j);
-            s *= tau[k];
-            for (int i = 0; i < len; i++) T_(r0 + i, j) -= s * vv[k][i];
-        }
-        for (int i = 0; i < j1 + nd; i++) {
-            double s = 0.0;
-            for (int j = 0; j < len; j++) s += T_(i, r0 + j) * vv[k][j];
-            s *= tau[k];
-            for (int j = 0; j < len; j++) T_(i, r0 + j) -= s * vv[k][j];
-        }
-        for (int i = 0; i < n; i++) {
-            double s = 0.0;
-            for (int j = 0; j < len; j++) s += Z_(i, r0 + j) * vv[k][j];
-            s *= tau[k];
-            for (int j = 0; j < len; j++) Z_(i, r0 + j) -= s * vv[k][j];
-        }
+        int const len = nd - k;
+        ap.emit(Op{j1 + k, (short)len, 0, hi, lo, vv[k][1], len > 2 ? vv[k][2] : 0.0, len > 3 ? vv[k][3] : 0.0, tau[k]}, j1, j1 + nd);
     }
     for (int i = n2; i < nd; i++) for (int j = 0; j < n2; j++) T_(j1 + i, j1 + j) = 0.0;
     // standardise the new 2x2 blocks
     auto standardise = [&](int p) {
         double rt1r, rt1i, rt2r, rt2i, cs, sn;
         lanv2(T_(p, p), T_(p, p + 1), T_(p + 1, p), T_(p + 1, p + 1), rt1r, rt1i, rt2r, rt2i, cs, sn);
-        rot_rows(T, ldt, p, p + 1, p + 2, n, cs, sn);
-        rot_cols(T, ldt, p, p + 1, 0, p, cs, sn);
-        rot_cols(Z, ldz, p, p + 1, 0, n, cs, sn);
+        ap.emit(Op{p, 2, 1, hi, lo, cs, sn, 0.0, 0.0}, p + 2, p);
     };
     if (n2 == 2) standardise(j1);
     if (n1 == 2) standardise(j1 + n2);
@@ -571,25 +365,32 @@ static int swap_blocks(int n, double *T, int ldt, double *Z, int ldz, int j1, in
 // Moves the diagonal block starting at row `from` up to row `to` (to <= from) by adjacent
 // swaps (LAPACK dtrexc, upward direction only; schur/cpu_utils.c:3377-3416).  Returns the
 // row where the block ended up (== to unless a swap was rejected).
-int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
+static int move_block_up(Applier &ap, int from, int to, int hi, int lo)
 {
+    int const n = ap.n, ldt = ap.ldt; double *const T = ap.T;
     int here = from;
     int nbf = (here + 1 < n && T_(here + 1, here) != 0.0) ? 2 : 1;
     while (here > to) {
         int nbabove = (here - 2 >= 0 && T_(here - 1, here - 2) != 0.0) ? 2 : 1;
         if (here - nbabove < to) break;       // `to` points into the middle of a block
         int j1 = here - nbabove;
-        if (swap_blocks(n, T, ldt, Z, ldz, j1, nbabove, nbf) != 0) break;
+        if (swap_blocks(ap, j1, nbabove, nbf, hi, lo) != 0) break;
         here = j1;
         if (nbf == 2 && T_(here + 1, here) == 0.0) {
             // the moving 2x2 block split into two 1x1 blocks: move them one at a time
-            int a = move_block_up(n, T, ldt, Z, ldz, here, to);
+            int a = move_block_up(ap, here, to, hi, lo);
             if (a != to) return a;
-            move_block_up(n, T, ldt, Z, ldz, here + 1, to + 1);
+            move_block_up(ap, here + 1, to + 1, hi, lo);
             return a;
         }
     }
+    ap.publish();
     return here;
+}
+int move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
+{
+    Applier ap{T, ldt, Z, ldz, n};
+    return move_block_up(ap, from, to, n, 0);
 }
 
 // ---- eigenvalue reordering inside one diagonal window (reorder/cpu.c reorder_window; LAPACK
@@ -676,38 +477,27 @@ int order_shifts(int n, double *wr, double *wi)
 // T is the nw x nw window (spike already embedded by the caller in the column to the left,
 // handled through `spike`): rows/cols [0, ns) are reduced, the reflectors are applied to
 // T(0:ns, ns:nw) from the left and accumulated into Z(:, 0:ns) from the right.
-static void hessenberg_small(int nw, int ns, double *T, int ldt, double *Z, int ldz)
+// `arena` receives the reflector vectors (the helpers read them until the next wait on the team).
+static void hessenberg_small(Applier &ap, int ns, double *arena)
 {
-    std::vector<double> v(ns);
+    int const ldt = ap.ldt; double *const T = ap.T;
     for (int k = 0; k + 2 < ns; k++) {
         int len = ns - k - 1;
+        double *v = arena; arena += len;
         for (int i = 0; i < len; i++) v[i] = T_(k + 1 + i, k);
-        double tau = house(len, v.data());
+        double tau = house(len, v);
         T_(k + 1, k) = v[0];
         for (int i = 1; i < len; i++) T_(k + 1 + i, k) = 0.0;
         if (tau == 0.0) continue;
         v[0] = 1.0;
-        // left: rows k+1..ns-1, columns k+1..nw-1
-        for (int j = k + 1; j < nw; j++) {
-            double s = 0.0;
-            for (int i = 0; i < len; i++) s += v[i] * T_(k + 1 + i, j);
-            s *= tau;
-            for (int i = 0; i < len; i++) T_(k + 1 + i, j) -= s * v[i];
-        }
-        // right: columns k+1..ns-1, rows 0..ns-1
-        for (int i = 0; i < ns; i++) {
-            double s = 0.0;
-            for (int j = 0; j < len; j++) s += T_(i, k + 1 + j) * v[j];
-            s *= tau;
-            for (int j = 0; j < len; j++) T_(i, k + 1 + j) -= s * v[j];
-        }
-        for (int i = 0; i < nw; i++) {
-            double s = 0.0;
-            for (int j = 0; j < len; j++) s += Z_(i, k + 1 + j) * v[j];
-            s *= tau;
-            for (int j = 0; j < len; j++) Z_(i, k + 1 + j) -= s * v[j];
-        }
+        // left: rows k+1..ns-1, columns k+1..nw-1 (right of ns: the helpers'); right: columns k+1..ns-1,
+        // rows 0..ns-1 (the rows above k+2 are not read again: the helpers'); Z
+        Op op{k + 1, (short)len, 2, ns, k + 2, 0.0, 0.0, 0.0, tau};
+        op_set_vector(op, v);
+        ap.emit(op, k + 1, ns);
+        if ((k & 3) == 3) ap.publish();
     }
+    ap.publish();
 }
 
 // ---- one deflation window of the blocked AED (schur/cpu.c:638-1006 starneig_cpu_deflate,
@@ -784,10 +574,31 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     bool const prof = tuning().aed_profile;
     static double t_schur = 0, t_reorder = 0, t_hess = 0; static int calls = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+#ifdef SN_TEST_HOOKS
+    // SN_AED_DUMP=<file> (test library only): every 6th window as it arrives, for replay off the GPU
+    // box (scratch/aed_replay.py).  Record: int32 nw, float64 sub, thres, then nw*nw column-major.
+    if (char const *path = getenv("SN_AED_DUMP")) {
+        static int seen = 0;
+        if (seen++ % 6 == 0 && seen < 6 * 48) {
+            if (FILE *f = fopen(path, "ab")) {
+                int32_t hdr = nw; fwrite(&hdr, 4, 1, f); fwrite(&sub, 8, 1, f); fwrite(&thres, 8, 1, f);
+                for (int j = 0; j < nw; j++) fwrite(&T_(0, j), 8, nw, f);
+                fclose(f);
+            }
+        }
+    }
+#endif
     double t0 = now();
     for (int j = 0; j < nw; j++) for (int i = 0; i < nw; i++) Z_(i, j) = (i == j) ? 1.0 : 0.0;
-    std::vector<double> wr(nw), wi(nw);
-    int info = small_schur(nw, T, ldt, Z, ldz, wr.data(), wi.data());
+    std::vector<double> wr(nw), wi(nw), z0(nw, 0.0);
+    z0[0] = 1.0;
+    // Z(0, :) -- all the deflation test reads of Z -- is kept on this thread; Z itself, and the parts of
+    // T the three phases below do not read again, may be behind (schur_host_team.h) until `whole`
+    Applier ap{T, ldt, Z, ldz, nw, team_for(nw), z0.data()};
+    ap.w.resize(nw);
+    struct Whole { Applier &a; ~Whole() { a.whole(); } } whole_on_return{ap};
+    if (ap.team) ap.team->begin(T, ldt, Z, ldz, nw);
+    int info = small_schur(ap, wr.data(), wi.data());
     int roof = 0;
     if (info != 0) {
         // rows [0, info) did not converge: only the trailing part is in Schur form
@@ -802,25 +613,28 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
         bool two = (top <= i - 1 && T_(i, i - 1) != 0.0);
         bool deflatable;
         if (thres > 0.0) {      // norm-stable criterion (cpu_utils.c:2891-2931)
-            deflatable = std::fabs(sub * Z_(0, i)) < thres &&
-                (!two || std::fabs(sub * Z_(0, i - 1)) < thres);
+            deflatable = std::fabs(sub * z0[i]) < thres &&
+                (!two || std::fabs(sub * z0[i - 1]) < thres);
         } else {                // LAPACK-style criterion (:2937-2988)
             double foo = std::fabs(T_(i, i));
             if (two) foo += std::sqrt(std::fabs(T_(i, i - 1))) * std::sqrt(std::fabs(T_(i - 1, i)));
             if (foo == 0.0) foo = std::fabs(sub);
-            double sp = std::fabs(sub * Z_(0, i));
-            if (two) sp = std::max(sp, std::fabs(sub * Z_(0, i - 1)));
+            double sp = std::fabs(sub * z0[i]);
+            if (two) sp = std::max(sp, std::fabs(sub * z0[i - 1]));
             deflatable = sp < std::max(smlnum, ulp * foo);
         }
         int bs = two ? 2 : 1;
         if (deflatable) i -= bs;
         else {
+            // on its way up the block only meets blocks in [top, i]: the columns right of i and the rows
+            // above top take no part in any later swap or test
             int from = i - bs + 1;
-            int at = move_block_up(nw, T, ldt, Z, ldz, from, top);
+            int at = move_block_up(ap, from, top, i + 1, top);
             if (at != top) { top = i + 1; break; }   // swap rejected: nothing below `i` deflates
             top += bs;
         }
     }
+    ap.whole_t();
     double t2 = now();
     res.deflated = nw - top;
     int ns = top;
@@ -828,44 +642,37 @@ AedResult aed_window(int nw, double *T, int ldt, double *Z, int ldz, double sub,
     if (ns - roof >= 2) res.shifts = extract_shifts(ns - roof, &T_(roof, roof), ldt, sr, si);
     else res.shifts = extract_shifts(nw, T, ldt, sr, si);
     // spike = sub * first row of Z
-    for (int j = 0; j < nw; j++) spike[j] = sub * Z_(0, j);
+    for (int j = 0; j < nw; j++) spike[j] = sub * z0[j];
+    ap.z0 = nullptr;
     if (res.deflated == 0 && roof == 0) return res;     // caller discards T/Z
     for (int j = ns; j < nw; j++) spike[j] = 0.0;        // deflated: below the threshold
+    std::vector<double> arena;
     if (ns > 1 && sub != 0.0) {
         // compress the spike to its first entry with one reflector, then restore Hessenberg
-        std::vector<double> v(ns);
+        arena.resize((size_t)ns * (ns + 3) / 2 + 8);
+        double *v = arena.data();
         for (int j = 0; j < ns; j++) v[j] = spike[j];
-        double tau = house(ns, v.data());
+        double tau = house(ns, v);
         spike[0] = v[0];
         for (int j = 1; j < ns; j++) spike[j] = 0.0;
         if (tau != 0.0) {
             v[0] = 1.0;
-            for (int j = 0; j < nw; j++) {           // left on rows [0,ns)
-                double s = 0.0;
-                for (int r = 0; r < ns; r++) s += v[r] * T_(r, j);
-                s *= tau;
-                for (int r = 0; r < ns; r++) T_(r, j) -= s * v[r];
-            }
-            for (int r = 0; r < ns; r++) {           // right on cols [0,ns), rows [0,ns)
-                double s = 0.0;
-                for (int j = 0; j < ns; j++) s += T_(r, j) * v[j];
-                s *= tau;
-                for (int j = 0; j < ns; j++) T_(r, j) -= s * v[j];
-            }
-            for (int r = 0; r < nw; r++) {
-                double s = 0.0;
-                for (int j = 0; j < ns; j++) s += Z_(r, j) * v[j];
-                s *= tau;
-                for (int j = 0; j < ns; j++) Z_(r, j) -= s * v[j];
-            }
+            // left on rows [0,ns) (columns right of ns: the helpers'), right on cols [0,ns), rows [0,ns); Z
+            Op op{0, (short)ns, 2, ns, 0, 0.0, 0.0, 0.0, tau};
+            op_set_vector(op, v);
+            ap.emit(op, 0, ns);
+            ap.publish();
         }
-        hessenberg_small(nw, ns, T, ldt, Z, ldz);
+        hessenberg_small(ap, ns, v + ns);
     }
+    ap.whole();
     if (prof) {
         t_schur += t1 - t0; t_reorder += t2 - t1; t_hess += now() - t2; calls++;
-        if (calls % 20 == 0)
-            fprintf(stderr, "[aed] calls %d schur %.2fs reorder %.2fs hess %.2fs (nw %d)\n",
-                calls, t_schur, t_reorder, t_hess, nw);
+        if (calls % 20 == 0) {
+            fprintf(stderr, "[aed] calls %d, the last 20 per call: schur %.2f ms, deflation %.2f ms, hessenberg %.2f ms (nw %d)\n",
+                calls, 50.0 * t_schur, 50.0 * t_reorder, 50.0 * t_hess, nw);
+            t_schur = t_reorder = t_hess = 0;
+        }
     }
     return res;
 }
@@ -882,7 +689,7 @@ __attribute__((visibility("default")))
 int sn_internal_move_block_up(int n, double *T, int ldt, double *Z, int ldz, int from, int to)
 { return sn::host::move_block_up(n, T, ldt, Z, ldz, from, to); }
 __attribute__((visibility("default")))
-void sn_internal_helper_session(int on) { sn::host::helper_session(on != 0); }
+void sn_internal_helper_session(int on) { sn::host::helper_session(on != 0, on > 1 ? on : 5); }
 __attribute__((visibility("default")))
 int sn_internal_deflate_window(int w, double *T, int ldt, double *Z, int ldz, double *spike, double sub,
     double thres, int carried, int *undeflated)

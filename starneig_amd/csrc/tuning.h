@@ -16,7 +16,7 @@ struct Tuning {
     // Schur
     bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
     int schur_lazy_batch = 32;      // SN_SCHUR_LAZY_BATCH
-    bool schur_helpers = false;     // SN_SCHUR_HELPERS: helper threads of the host window kernels
+    int schur_helpers = -1;         // SN_SCHUR_HELPERS: helper threads of the host window kernels (0 = none, -1 = five if the node has the cores)
     int schur_reuse = 0;            // SN_SCHUR_REUSE: fixed shift multiplicity (0 = adaptive)
     bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr

@@ -24,7 +24,7 @@ Tuning const &tuning()
         t.hess_side_cus = geti("SN_HESS_SIDE_CUS", 0);
         t.schur_nolazyrows = getb("SN_SCHUR_NOLAZYROWS");
         t.schur_lazy_batch = geti("SN_SCHUR_LAZY_BATCH", t.schur_lazy_batch);
-        t.schur_helpers = getb("SN_SCHUR_HELPERS");
+        t.schur_helpers = geti("SN_SCHUR_HELPERS", t.schur_helpers);
         t.schur_reuse = std::max(0, std::min(8, geti("SN_SCHUR_REUSE", 0)));
         t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
         t.schur_profile = getb("SN_SCHUR_PROFILE");

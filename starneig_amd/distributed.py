@@ -58,14 +58,14 @@ def native_rccl(group=None):
         L = lib.load()
         dev = torch.device("cuda", torch.cuda.current_device())
         ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            host = (C.c_ubyte * 128)()
-            if L.starneig_amd_rccl_unique_id(host) != 0:
-                host = None
-            else:
-                ident.copy_(torch.tensor(list(host), dtype=torch.uint8))
-        ok = torch.tensor([1 if (rank != 0 or host is not None) else 0], dtype=torch.int32, device=dev)
-        dist.broadcast(ok, src=0)
+        # every rank opens RCCL and makes an id (only rank 0's is used): ncclCommInitRank is a collective,
+        # so no rank may enter it unless all of them can
+        host = (C.c_ubyte * 128)()
+        loaded = L.starneig_amd_rccl_unique_id(host) == 0
+        if rank == 0 and loaded:
+            ident.copy_(torch.tensor(list(host), dtype=torch.uint8))
+        ok = torch.tensor([1 if loaded else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             return False
         dist.broadcast(ident, src=0)
