@@ -134,6 +134,13 @@ static int small_schur(Applier &ap, double *wr, double *wi)
     const int itmax = 30 * std::max(10, n), kexsh = 10;
     if (n == 0) return 0;
     for (int j = 0; j + 2 < n; j++) { T_(j + 2, j) = 0.0; if (j + 3 < n) T_(j + 3, j) = 0.0; }
+    Team *const tm = ap.team;
+    constexpr int LOOK = 16;        // measured flat between 8 and 24 (nw = 256, EPYC 9575F)
+    auto chunk_at = [&](int k) { return k / LOOK; };         // chunk c: the reflectors at rows [c LOOK, (c+1) LOOK) ...
+    auto bnd = [&](int c) { return c * LOOK + 2; };          // ... and the columns [bnd(c), bnd(c+1)): a reflector reaches two columns on
+    std::vector<unsigned> far_idx;      // per column: the log position after the last reflector whose helpers' share reaches it
+    Op held[LOOK]; int nheld = 0;   // the reflectors of the current chunk
+    if (tm) far_idx.assign(n, tm->pending);
     int i = n - 1;
     while (i >= 0) {
         int l = 0;
@@ -203,8 +210,30 @@ static int small_schur(Applier &ap, double *wr, double *wi)
                 if (std::fabs(T_(m, m - 1)) * (std::fabs(v[1]) + std::fabs(v[2])) <= ulp * std::fabs(v[0]) * nb)
                     break;
             }
+            // With a team the sweep also leaves the FAR columns of the active block to the helpers.  The
+            // columns are cut into chunks of LOOK at fixed positions; while the bulge is in chunk c the
+            // chain applies its reflectors at once to the columns up to the end of chunk c, LATER -- in
+            // one go, when the bulge enters chunk c+1 -- to the columns of chunk c+1, and not at all to
+            // the columns beyond, which the helpers update (Op::from) and hand back a chunk at a time:
+            // a chunk comes home when the bulge enters it, and what the helpers still owe it then was
+            // published a whole chunk of the chain's work earlier.
+            int c = chunk_at(m), imm = i + 1, lz = i + 1;
+            if (tm) { imm = std::min(bnd(c + 1), i + 1); lz = std::min(bnd(c + 2), i + 1); }
+            auto next_chunk = [&]() {
+                tm->publish();
+                unsigned const owed = lz > imm ? far_idx[lz - 1] : 0;       // before this chunk's own marks
+                for (int x = lz; x < n; x++) far_idx[x] = tm->pending;
+                if (lz > imm) {
+                    tm->wait_t_index(owed);
+                    for (int q = 0; q < nheld; q++) op_rows(T, ldt, held[q], imm, lz, 1);
+                }
+                nheld = 0;
+                c++;
+                imm = std::min(bnd(c + 1), i + 1); lz = std::min(bnd(c + 2), i + 1);
+            };
             for (int k2 = m; k2 <= i - 1; k2++) {
                 int nr = std::min(3, i - k2 + 1);
+                if (tm && k2 >= (c + 1) * LOOK) next_chunk();
                 if (k2 > m) { v[0] = T_(k2, k2 - 1); v[1] = T_(k2 + 1, k2 - 1); if (nr == 3) v[2] = T_(k2 + 2, k2 - 1); }
                 double t1 = house(nr, v);
                 if (k2 > m) { T_(k2, k2 - 1) = v[0]; T_(k2 + 1, k2 - 1) = 0.0; if (k2 < i - 1) T_(k2 + 2, k2 - 1) = 0.0; }
@@ -213,9 +242,14 @@ static int small_schur(Applier &ap, double *wr, double *wi)
                 // (The rows above l are not read again either, but they become "columns right of the
                 // active block" of a later, higher block: T(r, c) would then be one helper's as a row
                 // above and another's as a column to the right, and the order between the two is lost.)
-                ap.emit(Op{k2, (short)nr, 0, i + 1, 0, v[1], nr == 3 ? v[2] : 0.0, 0.0, t1}, k2, std::min(k2 + 3, i) + 1);
+                Op const op{k2, (short)nr, 0, lz, 0, v[1], nr == 3 ? v[2] : 0.0, 0.0, t1};
+                if (tm) { held[nheld++] = op; ap.emit_near(op, k2, imm, std::min(k2 + 3, i) + 1); }
+                else ap.emit(op, k2, std::min(k2 + 3, i) + 1);
             }
-            ap.publish();
+            if (tm) {
+                next_chunk();                       // the last chunk's later columns (column i can be one)
+                tm->wait_t_index(far_idx[i]);       // every column of the active block is whole again
+            }
         }
         if (!done) { ap.whole_t(); return i + 1; }
         if (l == i) { wr[i] = T_(i, i); wi[i] = 0.0; }
@@ -225,6 +259,7 @@ static int small_schur(Applier &ap, double *wr, double *wi)
                 wr[i - 1], wi[i - 1], wr[i], wi[i], cs, sn);
             // the 2x2 block itself is standardised by lanv2: columns right of it, rows above it
             ap.emit(Op{i - 1, 2, 1, i + 1, 0, cs, sn, 0.0, 0.0}, i + 1, i - 1);
+            if (tm) { tm->publish(); for (int x = i + 1; x < n; x++) far_idx[x] = tm->pending; }
         }
         i = l - 1;
     }

@@ -131,7 +131,12 @@ static inline void op_rows(double *X, int ldx, Op const &op, int j0, int j1, int
 
 // X(r0:r1, k:k+nr) <- X(r0:r1, k:k+nr) G: distinct columns, contiguous rows: the loops vectorise.
 // `w` (r1 doubles) is scratch for the long reflectors only.
-static inline void op_cols(double *X, int ldx, Op const &op, int r0, int r1, double *w = nullptr)
+// (Compiled twice: the library is built for x86-64-v3, the 512-bit clone is picked at load time where
+// the processor has it -- these loops are a quarter of the serial chain's time.)
+#ifndef __HIP_DEVICE_COMPILE__
+__attribute__((target_clones("arch=x86-64-v4", "default")))
+#endif
+static void op_cols(double *X, int ldx, Op const &op, int r0, int r1, double *w = nullptr)
 {
     if (r0 >= r1) return;
     double *__restrict__ c0 = X + (size_t)op.k * ldx, *__restrict__ c1 = c0 + ldx;
@@ -321,6 +326,12 @@ struct Team {
             while (tail[h].v.load(std::memory_order_acquire) != pending) _mm_pause();
     }
     void wait_t() { wait(nz, nz + nt); }                // T is whole again (Z may still be behind)
+    // the helpers of T have passed log position `idx` (which must have been published)
+    inline void wait_t_index(unsigned idx)
+    {
+        for (int h = nz; h < nz + nt; h++)
+            while ((int)(tail[h].v.load(std::memory_order_acquire) - idx) < 0) _mm_pause();
+    }
     void wait_all() { wait(0, nz + nt); }
 
     void run(int me)
@@ -374,7 +385,7 @@ struct Team {
     {
         count = std::max(2, std::min(count, (int)MAXH));
         std::lock_guard<std::mutex> lk(mu);
-        nz = std::max(1, (2 * count + 1) / 3); nt = count - nz;
+        nz = std::max(1, count / 3); nt = count - nz;        // the far columns of the active block are the larger share
         int seat[MAXH + 1];
         cpu_set_t allowed;
         pinned = pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) == 0 && seats.claim(count + 1, allowed, seat);
@@ -427,6 +438,15 @@ struct Applier {
             op_cols(Z, ldz, op, 0, n, w.data());
             if (z0) op_cols(z0, 1, op, 0, 1, w.data());
         }
+    }
+    // as `emit` with a team, but the calling thread only takes the columns [c0, near) of its share from
+    // the left now; the caller owes T(k:k+nr, near:from) itself
+    inline void emit_near(Op const &op, int c0, int near, int r1)
+    {
+        team->log(op);
+        op_rows(T, ldt, op, c0, near, 1);
+        op_cols(T, ldt, op, 0, r1, w.data());
+        if (z0) op_cols(z0, 1, op, 0, 1, w.data());
     }
     inline void publish() { if (team) team->publish(); }
     inline void whole_t() { if (team) team->wait_t(); }
