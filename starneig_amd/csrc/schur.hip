@@ -1220,8 +1220,11 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // 192 / 128 - 208 / 128 (2.15 s); explicit conf values are honoured up to 1024.
     int const helpers = level == 0 ? (tuning().schur_helpers >= 0 ? std::min(tuning().schur_helpers, prm.host_threads - 1)
                                                                  : (prm.host_threads >= 6 ? 5 : 0)) : 0;
-    nw_default = std::min(nw_default, helpers >= 2 ? 256 : 192);
-    ns_default = std::min(ns_default, helpers >= 2 ? 160 : 128);
+    // The balance moves with n (the sweeps get longer, the window kernel does not): 0.21 s at 192 / 128
+    // against 0.31 s at 256 / 160 for n = 4000, 0.46 s against 0.58 s for n = 8000.
+    int const nw_cap = std::min(helpers >= 2 ? 288 : 192, (136 + (int)(0.006 * n)) / 8 * 8);
+    nw_default = std::min(nw_default, nw_cap);
+    ns_default = std::min(ns_default, nw_cap * 5 / 8);
     // AED windows above the hard limit (process_args.c:372-398, default 300) are reduced by the
     // blocked device path (Driver::large_aed, row S5), the others by the sequential host kernel;
     // the private window of a blocked AED (level 1) always takes the small defaults

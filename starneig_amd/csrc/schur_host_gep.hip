@@ -28,35 +28,66 @@ namespace {
 
 inline double sgn(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::fabs(a); }
 
+// sqrt(a^2 + b^2): plain when both are far from the ends of the exponent range (always, in practice;
+// hypot costs several times the rest of a rotation)
+inline double norm2(double a, double b)
+{
+    double const x = std::fabs(a), y = std::fabs(b), hi = std::max(x, y), lo = std::min(x, y);
+    if (hi < 1e150 && (lo > 1e-150 || lo == 0.0)) return std::sqrt(x * x + y * y);
+    return std::hypot(a, b);
+}
+
 // Givens: [c s; -s c] [f; g] = [r; 0]
 inline void givens(double f, double g, double &c, double &s, double &r)
 {
     if (g == 0.0) { c = 1.0; s = 0.0; r = f; return; }
     if (f == 0.0) { c = 0.0; s = 1.0; r = g; return; }
-    r = std::hypot(f, g); c = f / r; s = g / r;
+    r = norm2(f, g); c = f / r; s = g / r;
 }
 
 struct Mat { double *p; int ld; inline double &operator()(int i, int j) const { return p[(size_t)j * ld + i]; } };
 
-// rows r1,r2 over columns [c0,c1): x' = c x + s y, y' = c y - s x
+// rows r1,r2 over columns [c0,c1): x' = c x + s y, y' = c y - s x.  (Row walks on a column-major matrix
+// do not vectorise; four columns are loaded before any is stored so that the compiler need not
+// serialise them.)
 inline void rot_rows(Mat M, int r1, int r2, int c0, int c1, double c, double s)
 {
-    for (int j = c0; j < c1; j++) { double x = M(r1, j), y = M(r2, j); M(r1, j) = c * x + s * y; M(r2, j) = c * y - s * x; }
+    int j = c0;
+    size_t const ld = M.ld;
+    for (; j + 4 <= c1; j += 4) {
+        double *p0 = M.p + (size_t)j * ld, *p1 = p0 + ld, *p2 = p1 + ld, *p3 = p2 + ld;
+        double x0 = p0[r1], y0 = p0[r2], x1 = p1[r1], y1 = p1[r2], x2 = p2[r1], y2 = p2[r2], x3 = p3[r1], y3 = p3[r2];
+        p0[r1] = c * x0 + s * y0; p0[r2] = c * y0 - s * x0;
+        p1[r1] = c * x1 + s * y1; p1[r2] = c * y1 - s * x1;
+        p2[r1] = c * x2 + s * y2; p2[r2] = c * y2 - s * x2;
+        p3[r1] = c * x3 + s * y3; p3[r2] = c * y3 - s * x3;
+    }
+    for (; j < c1; j++) { double x = M(r1, j), y = M(r2, j); M(r1, j) = c * x + s * y; M(r2, j) = c * y - s * x; }
 }
 inline void rot_cols(Mat M, int c1_, int c2_, int r0, int r1, double c, double s)
 {
-    double *a = &M(0, c1_), *b = &M(0, c2_);
+    double *__restrict__ a = &M(0, c1_), *__restrict__ b = &M(0, c2_);      // distinct columns: vectorises
     for (int i = r0; i < r1; i++) { double x = a[i], y = b[i]; a[i] = c * x + s * y; b[i] = c * y - s * x; }
 }
 
+// sqrt of the sum of squares of x[i0:i1): plain unless an entry is near the ends of the exponent range
+inline double norm_range(const double *x, int i0, int i1)
+{
+    double hi = 0.0, lo = DBL_MAX, ssq = 0.0;
+    for (int i = i0; i < i1; i++) { double a = std::fabs(x[i]); hi = std::max(hi, a); if (a != 0.0) lo = std::min(lo, a); ssq += a * a; }
+    if (hi == 0.0) return 0.0;
+    if (hi < 1e150 && lo > 1e-150) return std::sqrt(ssq);
+    double xn = 0.0;
+    for (int i = i0; i < i1; i++) xn = std::hypot(xn, x[i]);
+    return xn;
+}
 // Householder with the pivot FIRST: (I - tau v v^T) x = beta e_1, v[0] = 1
 inline double house_first(int n, const double *x, double *v, double &beta)
 {
-    double xn = 0.0;
-    for (int i = 1; i < n; i++) xn = std::hypot(xn, x[i]);
+    double xn = norm_range(x, 1, n);
     v[0] = 1.0;
     if (xn == 0.0) { for (int i = 1; i < n; i++) v[i] = 0.0; beta = x[0]; return 0.0; }
-    beta = -sgn(std::hypot(x[0], xn), x[0]);
+    beta = -sgn(norm2(x[0], xn), x[0]);
     double sc = 1.0 / (x[0] - beta);
     for (int i = 1; i < n; i++) v[i] = x[i] * sc;
     return (beta - x[0]) / beta;
@@ -64,11 +95,10 @@ inline double house_first(int n, const double *x, double *v, double &beta)
 // Householder with the pivot LAST: x^T (I - tau v v^T) = beta e_n^T, v[n-1] = 1
 inline double house_last(int n, const double *x, double *v, double &beta)
 {
-    double xn = 0.0;
-    for (int i = 0; i + 1 < n; i++) xn = std::hypot(xn, x[i]);
+    double xn = norm_range(x, 0, n - 1);
     v[n - 1] = 1.0;
     if (xn == 0.0) { for (int i = 0; i + 1 < n; i++) v[i] = 0.0; beta = x[n - 1]; return 0.0; }
-    beta = -sgn(std::hypot(x[n - 1], xn), x[n - 1]);
+    beta = -sgn(norm2(x[n - 1], xn), x[n - 1]);
     double sc = 1.0 / (x[n - 1] - beta);
     for (int i = 0; i + 1 < n; i++) v[i] = x[i] * sc;
     return (beta - x[n - 1]) / beta;
@@ -77,22 +107,78 @@ inline double house_last(int n, const double *x, double *v, double &beta)
 inline void refl_left(Mat M, int r0, int len, int c0, int c1, const double *v, double tau)
 {
     if (tau == 0.0) return;
+    if (len == 3) {
+        double const v0 = v[0], v1 = v[1], v2 = v[2], t0 = tau * v0, t1 = tau * v1, t2 = tau * v2;
+        size_t const ld = M.ld;
+        int j = c0;
+        for (; j + 4 <= c1; j += 4) {
+            double *p0 = M.p + (size_t)j * ld + r0, *p1 = p0 + ld, *p2 = p1 + ld, *p3 = p2 + ld;
+            double a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+            double e0 = p2[0], e1 = p2[1], e2 = p2[2], d0 = p3[0], d1 = p3[1], d2 = p3[2];
+            double sa = v0 * a0 + v1 * a1 + v2 * a2, sb = v0 * b0 + v1 * b1 + v2 * b2;
+            double se = v0 * e0 + v1 * e1 + v2 * e2, sd = v0 * d0 + v1 * d1 + v2 * d2;
+            p0[0] = a0 - sa * t0; p0[1] = a1 - sa * t1; p0[2] = a2 - sa * t2;
+            p1[0] = b0 - sb * t0; p1[1] = b1 - sb * t1; p1[2] = b2 - sb * t2;
+            p2[0] = e0 - se * t0; p2[1] = e1 - se * t1; p2[2] = e2 - se * t2;
+            p3[0] = d0 - sd * t0; p3[1] = d1 - sd * t1; p3[2] = d2 - sd * t2;
+        }
+        for (; j < c1; j++) {
+            double *p = M.p + (size_t)j * ld + r0;
+            double a0 = p[0], a1 = p[1], a2 = p[2], sa = v0 * a0 + v1 * a1 + v2 * a2;
+            p[0] = a0 - sa * t0; p[1] = a1 - sa * t1; p[2] = a2 - sa * t2;
+        }
+        return;
+    }
     for (int j = c0; j < c1; j++) {
+        double *__restrict__ x = &M(r0, j);
         double s = 0.0;
-        for (int i = 0; i < len; i++) s += v[i] * M(r0 + i, j);
+        for (int i = 0; i < len; i++) s += v[i] * x[i];
         s *= tau;
-        for (int i = 0; i < len; i++) M(r0 + i, j) -= s * v[i];
+        for (int i = 0; i < len; i++) x[i] -= s * v[i];
     }
 }
-// M(r0:r1, c0:c0+len) <- M (I - tau v v^T)
+// M(r0:r1, c0:c0+len) <- M (I - tau v v^T): column sweeps over contiguous rows
 inline void refl_right(Mat M, int c0, int len, int r0, int r1, const double *v, double tau)
 {
-    if (tau == 0.0) return;
-    for (int i = r0; i < r1; i++) {
-        double s = 0.0;
-        for (int j = 0; j < len; j++) s += M(i, c0 + j) * v[j];
-        s *= tau;
-        for (int j = 0; j < len; j++) M(i, c0 + j) -= s * v[j];
+    if (tau == 0.0 || r1 <= r0) return;
+    if (len == 3) {
+        double *__restrict__ x0 = &M(0, c0), *__restrict__ x1 = &M(0, c0 + 1), *__restrict__ x2 = &M(0, c0 + 2);
+        double const v0 = v[0], v1 = v[1], v2 = v[2], t0 = tau * v0, t1 = tau * v1, t2 = tau * v2;
+        for (int i = r0; i < r1; i++) {
+            double s = x0[i] * v0 + x1[i] * v1 + x2[i] * v2;
+            x0[i] -= s * t0; x1[i] -= s * t1; x2[i] -= s * t2;
+        }
+        return;
+    }
+    if (len == 2) {
+        double *__restrict__ x0 = &M(0, c0), *__restrict__ x1 = &M(0, c0 + 1);
+        double const v0 = v[0], v1 = v[1], t0 = tau * v0, t1 = tau * v1;
+        for (int i = r0; i < r1; i++) {
+            double s = x0[i] * v0 + x1[i] * v1;
+            x0[i] -= s * t0; x1[i] -= s * t1;
+        }
+        return;
+    }
+    if (len == 4) {
+        double *__restrict__ x0 = &M(0, c0), *__restrict__ x1 = &M(0, c0 + 1), *__restrict__ x2 = &M(0, c0 + 2), *__restrict__ x3 = &M(0, c0 + 3);
+        double const v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], t0 = tau * v0, t1 = tau * v1, t2 = tau * v2, t3 = tau * v3;
+        for (int i = r0; i < r1; i++) {
+            double s = x0[i] * v0 + x1[i] * v1 + x2[i] * v2 + x3[i] * v3;
+            x0[i] -= s * t0; x1[i] -= s * t1; x2[i] -= s * t2; x3[i] -= s * t3;
+        }
+        return;
+    }
+    thread_local std::vector<double> w;
+    if ((int)w.size() < r1) w.resize(r1);
+    double *__restrict__ ww = w.data();
+    for (int i = r0; i < r1; i++) ww[i] = 0.0;
+    for (int j = 0; j < len; j++) {
+        double const *__restrict__ x = &M(0, c0 + j); double const vj = v[j];
+        for (int i = r0; i < r1; i++) ww[i] += x[i] * vj;
+    }
+    for (int j = 0; j < len; j++) {
+        double *__restrict__ x = &M(0, c0 + j); double const tv = tau * v[j];
+        for (int i = r0; i < r1; i++) x[i] -= ww[i] * tv;
     }
 }
 
@@ -443,6 +529,35 @@ static void small_qr(int m, int k, double const *X, double *Uo)
 //   A11 R - L A22 = -A12,  B11 R - L B22 = -B12   (right: [R; I], left: [L; I]),
 // solved as a dense system of 2 n1 n2 <= 8 unknowns with complete pivoting.  Returns false
 // (nothing changed) when the blocks are too close to swap stably (LAPACK's weak stability test).
+// M(0:rows, j:j+m) <- M(0:rows, j:j+m) W, W m x m (m <= 4) with leading dimension 4: the columns are
+// distinct and the rows contiguous, so the row loop vectorises
+template <int MM>
+static void right_apply_m(Mat M, int rows, int j, const double *W)
+{
+    double *__restrict__ x0 = &M(0, j), *__restrict__ x1 = &M(0, j + 1);
+    double *__restrict__ x2 = MM > 2 ? &M(0, j + 2) : nullptr, *__restrict__ x3 = MM > 3 ? &M(0, j + 3) : nullptr;
+    for (int r = 0; r < rows; r++) {
+        double const a0 = x0[r], a1 = x1[r], a2 = MM > 2 ? x2[r] : 0.0, a3 = MM > 3 ? x3[r] : 0.0;
+        double o[4];
+        #pragma unroll
+        for (int c = 0; c < MM; c++) {
+            double v = a0 * W[0 + 4 * c] + a1 * W[1 + 4 * c];
+            if (MM > 2) v += a2 * W[2 + 4 * c];
+            if (MM > 3) v += a3 * W[3 + 4 * c];
+            o[c] = v;
+        }
+        x0[r] = o[0]; x1[r] = o[1];
+        if (MM > 2) x2[r] = o[2];
+        if (MM > 3) x3[r] = o[3];
+    }
+}
+static void right_apply(Mat M, int rows, int j, int m, const double *W)
+{
+    if (m == 2) right_apply_m<2>(M, rows, j, W);
+    else if (m == 3) right_apply_m<3>(M, rows, j, W);
+    else right_apply_m<4>(M, rows, j, W);
+}
+
 static bool gep_swap_adjacent(int nw, Mat A, Mat B, Mat Q, Mat Z, int nq, int j, int n1, int n2)
 {
     int const m = n1 + n2, nn = n1 * n2, N = 2 * nn;
@@ -529,17 +644,8 @@ static bool gep_swap_adjacent(int nw, Mat A, Mat B, Mat Q, Mat Z, int nq, int j,
         for (int r = 0; r < m; r++) { double a = 0.0; for (int p = 0; p < m; p++) a += Ql[p + 4 * r] * B(j + p, c); tmp[r] = a; }
         for (int r = 0; r < m; r++) B(j + r, c) = tmp[r];
     }
-    auto right = [&](Mat M, int rows) {
-        for (int r = 0; r < rows; r++) {
-            for (int c = 0; c < m; c++) { double a = 0.0; for (int p = 0; p < m; p++) a += M(r, j + p) * Zl[p + 4 * c]; tmp[c] = a; }
-            for (int c = 0; c < m; c++) M(r, j + c) = tmp[c];
-        }
-    };
-    right(A, j + m); right(B, j + m); right(Z, nq);
-    for (int r = 0; r < nq; r++) {
-        for (int c = 0; c < m; c++) { double a = 0.0; for (int p = 0; p < m; p++) a += Q(r, j + p) * Ql[p + 4 * c]; tmp[c] = a; }
-        for (int c = 0; c < m; c++) Q(r, j + c) = tmp[c];
-    }
+    right_apply(A, j + m, j, m, Zl); right_apply(B, j + m, j, m, Zl); right_apply(Z, nq, j, m, Zl);
+    right_apply(Q, nq, j, m, Ql);
     for (int c = 0; c < n2; c++) for (int r = n2; r < m; r++) { A(j + r, j + c) = 0.0; B(j + r, j + c) = 0.0; }
     // ---- restore the standard form of the two diagonal blocks
     auto fix_block = [&](int p, int bs) {

@@ -296,7 +296,7 @@ struct Team {
     bool session = false, quit = false, pinned = false;
     cpu_set_t caller_mask;
     Seats seats;
-    int started = 0;
+    int started = 0, parked = 0;        // (parked: under `mu`)
 
     void begin(double *T_, int ldt_, double *Z_, int ldz_, int n_)
     {
@@ -340,7 +340,9 @@ struct Team {
         for (;;) {
             {   // parked between sessions
                 std::unique_lock<std::mutex> lk(mu);
+                parked++;
                 cv.wait(lk, [&] { return (session && me < nz + nt) || quit; });
+                parked--;
                 if (quit) return;
             }
             unsigned idle = 0;
@@ -384,6 +386,14 @@ struct Team {
     void open(int count)
     {
         count = std::max(2, std::min(count, (int)MAXH));
+        if (started && count != nz + nt) {
+            // another division of the work: every helper of the last session has to be parked first (one
+            // that is still spinning would go on with its old share next to the new owners of it)
+            for (;;) {
+                { std::lock_guard<std::mutex> lk(mu); if (parked == started) break; }
+                std::this_thread::yield();
+            }
+        }
         std::lock_guard<std::mutex> lk(mu);
         nz = std::max(1, count / 3); nt = count - nz;        // the far columns of the active block are the larger share
         int seat[MAXH + 1];

@@ -2,6 +2,7 @@
 reduction, block reordering, shift extraction, AED window) through internal hooks of the
 library -- no GPU involved.  Checked against numpy/LAPACK and the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -158,9 +159,9 @@ def test_reorder_window_moves_selected_blocks_to_the_top(n, seed):
 
 @pytest.mark.parametrize("n", [48, 97, 160, 300])
 def test_helper_threads_reproduce_the_serial_kernels_bit_for_bit(n):
-    """small_schur / aed_window with the Z accumulation and the left updates of the converged
-    columns handed to two helper threads (schur_host.hip, `Helpers`): every entry sees the same
-    operations in the same order, so T, Z and the eigenvalues equal the serial results exactly."""
+    """small_schur / aed_window with Z, the far columns of the active block and the columns right of it
+    handed to the helper team (schur_host_team.h): every entry sees the same operations in the same
+    order, so T, Z and the eigenvalues equal the serial results exactly."""
     L = lib()
     L.sn_internal_helper_session.argtypes = [C.c_int]
     H0 = hess_input(n, seed=11)
@@ -186,6 +187,43 @@ def test_helper_threads_reproduce_the_serial_kernels_bit_for_bit(n):
     L.sn_internal_helper_session(0)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_aed_window_on_windows_captured_from_the_baseline_reduction(which):
+    """Two AED windows as they arrive during the n = 20000 reduction (tests/golden/make_aed_windows.py):
+    unlike a random Hessenberg matrix they deflate about half of their eigenvalues, so the swaps of the
+    deflation phase and the re-reduction to Hessenberg form carry real work.  The invariants of
+    test_aed_window_invariants, and the serial kernel against the helper team (schur_host_team.h: far
+    columns, rows above, Z and the re-Hessenberg updates on other threads) bit for bit."""
+    L = lib()
+    L.sn_internal_helper_session.argtypes = [C.c_int]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aed_windows_lcg20000.npz"))
+    W0 = np.asfortranarray(g["windows"][which]); sub = float(g["subs"][which]); thres = float(g["thres"][which])
+    nw = W0.shape[0]
+    res = []
+    for helpers in (0, 5, 3):
+        L.sn_internal_helper_session(helpers)
+        ld = nw + 8                                   # the driver's leading dimension
+        Tb = np.zeros((ld, nw), order="F"); Tb[:nw] = W0
+        Zb = np.zeros((ld, nw), order="F")
+        spike = np.zeros(nw); sr = np.zeros(nw); si = np.zeros(nw); out = (C.c_int * 3)()
+        L.sn_internal_aed_window(nw, P(Tb), ld, P(Zb), ld, sub, thres, P(spike), P(sr), P(si), out)
+        L.sn_internal_helper_session(0)
+        res.append((Tb[:nw].copy(), Zb[:nw].copy(), spike, tuple(out)))
+    T, Z, spike, (nd, nshift, failed) = res[0]
+    assert failed == 0 and 40 <= nd <= nw - 40
+    ns = nw - nd
+    assert np.linalg.norm(Z @ Z.T - np.eye(nw)) <= 500 * U * np.sqrt(nw)
+    assert np.linalg.norm(Z @ T @ Z.T - W0) <= 1000 * U * np.linalg.norm(W0)
+    assert np.all(np.tril(T[:ns, :ns], -2) == 0.0) and np.all(T[ns:, :ns] == 0.0)
+    assert is_quasi_triangular(T[ns:, ns:])
+    full = sub * Z[0, :]
+    assert np.all(spike[1:] == 0.0) and np.all(np.abs(full[ns:]) < thres)
+    assert abs(abs(spike[0]) - np.linalg.norm(full[:ns])) <= 100 * U * abs(sub)
+    for Tt, Zt, st, ot in res[1:]:
+        assert ot == res[0][3] and np.array_equal(st, spike)
+        assert np.array_equal(Tt, T) and np.array_equal(Zt, Z)
 
 
 def test_reorder_window_rejected_swap_keeps_a_valid_decomposition():
