@@ -665,7 +665,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     // pencil) window 64 / nibble 6 % needs 880 AEDs of 1.8 ms and only 4 sweeps -- 1.9 s and a
     // residual of 74 u, against 7.0 s and 499 u for window 160 / nibble 40 % (137 sweeps).
     // If the AEDs stop deflating (less than 6 % of the window) the sweeps take over as usual.
-    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 768) : std::min(64, std::max(16, n / 8));
+    int const nw_rule = tuning().gep_window > 0 ? tuning().gep_window : 64;
+    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 768) : std::min(nw_rule, std::max(16, n / 8));
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : std::min(100, std::max(2, 2 * nw_conf / 3));
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
     ns_conf = std::max(2, ns_conf - ns_conf % 2);

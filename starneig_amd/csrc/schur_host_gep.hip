@@ -16,6 +16,9 @@
 // Reordering inside the AED window swaps adjacent blocks through the generalized
 // Sylvester equation like LAPACK dtgex2.
 #include "schur_host.h"
+#include "tuning.h"
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -562,12 +565,21 @@ static bool gep_swap_adjacent(int nw, Mat A, Mat B, Mat Q, Mat Z, int nq, int j,
 {
     int const m = n1 + n2, nn = n1 * n2, N = 2 * nn;
     double S[16], T[16];
-    double fro = 0.0;
+    // Frobenius norm of the local pencil: a plain sum of squares unless an entry is near the ends of the
+    // exponent range (32 hypot calls cost more than the rest of a 1x1-1x1 swap)
+    double fro = 0.0, big = 0.0;
     for (int c = 0; c < m; c++)
         for (int r = 0; r < m; r++) {
-            S[r + 4 * c] = A(j + r, j + c); T[r + 4 * c] = B(j + r, j + c);
-            fro = std::hypot(fro, std::hypot(S[r + 4 * c], T[r + 4 * c]));
+            double const a = A(j + r, j + c), b = B(j + r, j + c);
+            S[r + 4 * c] = a; T[r + 4 * c] = b;
+            fro += a * a + b * b; big = std::max(big, std::max(std::fabs(a), std::fabs(b)));
         }
+    bool const plain = big < 1e140 && big > 1e-140;
+    if (plain) fro = std::sqrt(fro);
+    else {
+        fro = 0.0;
+        for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) fro = std::hypot(fro, std::hypot(S[r + 4 * c], T[r + 4 * c]));
+    }
     double K[64], u[8];
     for (int i = 0; i < 64; i++) K[i] = 0.0;
     for (int k = 0; k < n2; k++)
@@ -633,8 +645,9 @@ static bool gep_swap_adjacent(int nw, Mat A, Mat B, Mat Q, Mat Z, int nq, int j,
             double a = 0.0, b = 0.0;
             for (int p = 0; p < m; p++) { a += Ql[p + 4 * r] * SZ[p + 4 * c]; b += Ql[p + 4 * r] * TZ[p + 4 * c]; }
             S2[r + 4 * c] = a; T2[r + 4 * c] = b;
-            if (r >= n2 && c < n2) low = std::hypot(low, std::hypot(a, b));
+            if (r >= n2 && c < n2) { if (plain) low += a * a + b * b; else low = std::hypot(low, std::hypot(a, b)); }
         }
+    if (plain) low = std::sqrt(low);
     if (low > std::max(20.0 * DBL_EPSILON * fro, DBL_MIN)) return false;
     // ---- apply to the window: rows j..j+m-1 <- Ql^T ., columns j..j+m-1 <- . Zl
     double tmp[4];
@@ -713,8 +726,13 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
     Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
     for (int j = 0; j < nw; j++) for (int i = 0; i < nw; i++) { Q(i, j) = (i == j); Z(i, j) = (i == j); }
     std::vector<double> ar(nw), ai(nw), be(nw);
+    bool const prof = tuning().aed_profile;
+    static double t_schur = 0, t_reorder = 0, t_rest = 0; static int calls = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double const t0 = prof ? now() : 0.0;
     int info = gep_small_schur(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, ar.data(), ai.data(), be.data());
     if (info != 0) { res.failed = 1; return res; }
+    double const t1 = prof ? now() : 0.0;
     // deflation scan from the bottom; undeflatable blocks are moved to the top of the window
     // (they accumulate in [0, top)) so that every converged eigenvalue can be deflated
     int top = 0, i = nw - 1;
@@ -743,6 +761,15 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
     }
     int const ns = top, nd = nw - top;
     res.deflated = nd;
+    double const t2 = prof ? now() : 0.0;
+    struct Report { bool on; double a, b, c; decltype(now) &clk; int nw, nd; ~Report() {
+        if (!on) return;
+        t_schur += b - a; t_reorder += c - b; t_rest += clk() - c; calls++;
+        if (calls % 50 == 0) {
+            fprintf(stderr, "[gep aed] calls %d, the last 50 per call: QZ %.3f ms, deflation %.3f ms, shifts + restoration %.3f ms (nw %d, last deflated %d)\n",
+                calls, 20.0 * t_schur, 20.0 * t_reorder, 20.0 * t_rest, nw, nd);
+            t_schur = t_reorder = t_rest = 0;
+        } } } report{prof, t0, t1, t2, now, nw, nd};
     for (int j = 0; j < nw; j++) spike[j] = sub * Q(0, j);
     // shifts: finite eigenvalues of the undeflated part (of everything if that is too small)
     {

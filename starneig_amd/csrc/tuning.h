@@ -30,6 +30,7 @@ struct Tuning {
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 1;              // SN_GEP_REUSE
+    int gep_window = 0;             // SN_GEP_WINDOW: default AED window of the QZ path (0 = the built-in rule)
 };
 
 Tuning const &tuning();
