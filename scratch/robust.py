@@ -5,7 +5,7 @@ import numpy as np, scipy.linalg as sl
 import starneig_amd as S, oracle as O
 import torch
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
-S.node_init(1,1,S.NO_MESSAGES)
+S.node_init(int(os.environ.get("SN_CORES", "1")),1,S.NO_MESSAGES)
 def run(name, H0):
     n = H0.shape[0]
     H = np.asfortranarray(H0.copy()); Q = np.asfortranarray(np.eye(n))
