@@ -133,7 +133,7 @@ static inline void op_rows(double *X, int ldx, Op const &op, int j0, int j1, int
 // `w` (r1 doubles) is scratch for the long reflectors only.
 // (Compiled twice: the library is built for x86-64-v3, the 512-bit clone is picked at load time where
 // the processor has it -- these loops are a quarter of the serial chain's time.)
-#ifndef __HIP_DEVICE_COMPILE__
+#if !defined(__HIP_DEVICE_COMPILE__) && !defined(SN_NO_TARGET_CLONES)    // (ifunc resolvers run before a sanitizer is up)
 __attribute__((target_clones("arch=x86-64-v4", "default")))
 #endif
 static void op_cols(double *X, int ldx, Op const &op, int r0, int r1, double *w = nullptr)
