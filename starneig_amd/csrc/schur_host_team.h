@@ -382,7 +382,7 @@ struct Team {
             }
         }
     }
-    // helpers: `count` threads, the first two thirds on Z (its update is the larger one)
+    // helpers: `count` threads, a third of them (at least one) on Z, the others on T
     void open(int count)
     {
         count = std::max(2, std::min(count, (int)MAXH));
