@@ -240,6 +240,41 @@ def test_device_resident_chain_exercises_update_zones(node, n, conf_vals):
     assert abs(results[0][2].sum() - float(torch.diagonal(tA0[:, :n]).sum())) <= 1e-9 * n
 
 
+@pytest.mark.parametrize("n,conf_vals", [(4000, (200, 120, 256)), (6000, (256, 160, 256))])
+def test_helper_team_of_the_window_kernel_in_situ(node, n, conf_vals):
+    """starneig_node_init with six cores or more switches the host window kernel to a serial chain plus
+    helper threads (csrc/schur_host_team.h; what bench.py runs).  Every element still sees the same factors
+    in the same order, so with the SAME configuration the whole reduction -- T, Q, the eigenvalues -- must
+    equal the one-core run bit for bit, and it must do so twice (the helpers' timing may not matter)."""
+    import torch
+    tA0 = node.device_matrix(n)
+    assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
+    tH0 = tA0.clone(); tQ0 = node.device_matrix(n)
+    node.set_matrix_device(tQ0, n, n, 0.0, 1.0)
+    assert node.hessenberg_device(tH0, tQ0, n=n) == 0
+    conf = node.schur_init_conf()
+    conf.aed_window_size, conf.shift_count, conf.small_limit = conf_vals
+    results = []
+    try:
+        for cores in (1, 8, 8):
+            node.node_finalize()
+            node.node_init(cores, 1, node.NO_MESSAGES)
+            tH, tQ = tH0.clone(), tQ0.clone()
+            rc, real, imag, st = node.schur_device(tH, tQ, n=n, conf=conf)
+            torch.cuda.synchronize()
+            assert rc == 0 and st["aeds"] > 0
+            results.append((tH, tQ, real, imag, st["aeds"], st["sweeps"]))
+    finally:
+        node.node_finalize()
+        node.node_init(1, 1, node.NO_MESSAGES)
+    rc, chk = node.check_device(results[1][1], results[1][0], tA0, n=n)
+    assert rc == 0 and chk["residual_u"] < WARN_U and chk["orthogonality_u"] < WARN_U
+    for other in results[1:]:
+        assert other[4:] == results[0][4:]
+        assert torch.equal(other[0], results[0][0]) and torch.equal(other[1], results[0][1])
+        assert np.array_equal(other[2], results[0][2]) and np.array_equal(other[3], results[0][3])
+
+
 def test_device_schur_without_q(node):
     """dQ = NULL: no accumulation (the lazy Q stream is idle); eigenvalues equal the run with Q"""
     import torch
