@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import starneig_amd as S
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
-S.node_init(1, 1, S.NO_MESSAGES)
+S.node_init(int(os.environ.get("SN_CORES", "16")), 1, S.NO_MESSAGES)
 n = int(sys.argv[1])
 tA0 = S.device_matrix(n); S.lcg_fill_device(tA0, n, n)
 tH0 = tA0.clone(); tQ0 = S.device_matrix(n); S.set_matrix_device(tQ0, n, n, 0.0, 1.0)
 S.hessenberg_device(tH0, tQ0, n=n)
-for name, cfg in (("default", None), ("reference sizes", (int(0.08 * n), int(0.06 * n) // 2 * 2))):
+for name, cfg in (("warm-up", None), ("default", None), ("reference sizes", (int(0.08 * n), int(0.06 * n) // 2 * 2))):
     conf = None
     if cfg:
         conf = S.schur_init_conf(); conf.aed_window_size, conf.shift_count = cfg

@@ -30,7 +30,8 @@ namespace sn {
 namespace {
 
 constexpr int RW_MAX = 128;         // window rows: the in-place update tiles own a whole window
-constexpr int RW_LD = RW_MAX;       // leading dimension of a window's T / Z block in the staging buffers
+constexpr int RW_LD = RW_MAX + 8;   // leading dimension of a window's T / Z block in the staging buffers: an odd number of
+                                    // cache lines (128 doubles are 16 lines: the row walks of the host swaps would live in 4 L1 sets)
 
 struct WinMeta { int wb, w; };
 

@@ -438,8 +438,8 @@ struct SchurWorkspace {
         SN_HIP_CHECK(hipMalloc((void **)&dAggGq, (size_t)agg_tcap * AGG_W * AGG_W * 8));
         SN_HIP_CHECK(hipHostMalloc((void **)&hAggTiles, (size_t)AGG_DESC_RING * sizeof(AggTile), hipHostMallocDefault));
         agg_desc_head = 0; std::fill(agg_desc_flush.begin(), agg_desc_flush.end(), -1L);
-        SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)(nwmax + 8) * nwmax * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)(nwmax + 24) * nwmax * 8, hipHostMallocDefault));
+        SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)(nwmax + 24) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hShift, (size_t)4 * 8 * nwmax * 8, hipHostMallocDefault));
         if (!attr_set) {
@@ -652,7 +652,9 @@ struct Driver {
     // host copies of a window use a padded leading dimension: w*8 bytes is a multiple of 512 for
     // the usual window sizes and the row walks of the sequential kernels would hit a handful
     // of cache sets (measured: 1.5x on the AED kernel at w = 192)
-    static int host_ld(int w) { return w + 8; }
+    // (w + 8 is not enough: 184 + 8 = 192 doubles are 24 cache lines, and a stride of 24 lines reaches 8 of
+    // the 64 L1 sets -- the AED kernel took 4.6 ms at 184 rows against 3.7 ms at 192.  An ODD number of lines.)
+    static int host_ld(int w) { int ld = (w + 8 + 7) / 8 * 8; if ((ld / 8) % 2 == 0) ld += 8; return ld; }
 
     // small dense Schur problem on a host copy (row S6; schur/cpu.c:402-496)
     int small_block(int lo, int w, double *real, double *imag)
@@ -1302,29 +1304,19 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     d.ts = s;
     d.nq = (q_rows >= 0) ? q_rows : n;
     d.spw_cap = prm.shifts_per_window;
-    // The multiplicity adapts to how the iteration converges.  On quickly converging (random
-    // dense) inputs the AEDs chain between two sweeps -- 11 of them per sweep at n = 20000, 7 at
-    // n = 8000 -- and repeated shifts cut the number of sweeps; on slowly converging structured
-    // inputs (all-ones Hessenberg, Toeplitz tridiagonal: 3-4 AEDs per sweep at full multiplicity)
-    // they only add chain passes, i.e. rounding error (n = 8000: residual 1205 u at a fixed
-    // multiplicity of 4, 737 u at 1; LAPACK dhseqr on the same matrix: 333 u).  Rule: full
-    // multiplicity to begin with; whenever four consecutive sweeps were preceded by fewer than
-    // 5 AEDs on average it is switched off for the rest of the reduction.
-    int aeds_since_sweep = 0, group_sweeps = -1, group_aeds = 0;
-    bool multiplicity_on = true;
+    // (Round 2 switched the multiplicity off on slowly converging inputs -- fewer than 5 AEDs per sweep
+    // over four sweeps -- because the extra chain passes cost accuracy there: all-ones Hessenberg,
+    // n = 8000, 1205 u at a multiplicity of 4 against 737 u at 1.  Since the reflectors are scaled by
+    // exact powers of two the same matrices lose 10-30 u (all-ones 165 -> 176 u, Toeplitz 177 -> 207 u,
+    // companion 391 -> 388 u) and gain a third of the time (1.26 -> 0.80 s); and with the larger AED
+    // windows of round 3 the rule misfired on random matrices whose chains are short in AEDs because each
+    // AED deflates more (n = 8000 at 184 rows: 29 sweeps instead of 10).  It is gone.)
+    int aeds_since_sweep = 0;
     auto replicate = [&](int nsh) {
-        if (!reuse_env && multiplicity_on) {
-            if (group_sweeps >= 0) group_aeds += aeds_since_sweep;     // (the first sweep's chain does not count)
-            if (++group_sweeps == 4) {
-                if (group_aeds < 20) multiplicity_on = false;
-                group_sweeps = 0; group_aeds = 0;
-            }
-        }
         aeds_since_sweep = 0;
-        int const m = (reuse_env || multiplicity_on) ? reuse : 1;
-        for (int r = 1; r < m; r++)
+        for (int r = 1; r < reuse; r++)
             for (int k = 0; k < nsh; k++) { sr[r * nsh + k] = sr[k]; si[r * nsh + k] = si[k]; }
-        return nsh * m;
+        return nsh * reuse;
     };
     auto finish_lookahead = [&](int ihi_now) {
         if (tuning().schur_profile && d.prof_la_ev && d.prof_la_t0 > 0) {

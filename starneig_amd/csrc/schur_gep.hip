@@ -304,7 +304,7 @@ struct GepWorkspace {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
         n = n_; nwmax = nw_; max_chains = chains_;
-        size_t const w2 = (size_t)(nwmax + 8) * nwmax * 8;
+        size_t const w2 = (size_t)(nwmax + 24) * nwmax * 8;
         ring = std::min(EV_RING, std::max(64, 4 * (n / 30 + 128)));
         std::fill(slot_flush.begin(), slot_flush.end(), -1L);
         SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)ring * max_chains * 2 * GWS * GWS * 8));
@@ -423,7 +423,7 @@ struct GepDriver {
     }
 
     // padded host leading dimension (see schur.hip)
-    static int host_ld(int w) { return w + 8; }
+    static int host_ld(int w) { int ld = (w + 8 + 7) / 8 * 8; if ((ld / 8) % 2 == 0) ld += 8; return ld; }    // an odd number of cache lines (schur.hip)
     void download_windows(int lo, int w)
     {
         double t0 = wall();
