@@ -1246,16 +1246,6 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 40;
     int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
 
-    // Helper threads of the host window kernels (schur_host.hip) for the duration of this reduction:
-    // opt-in (SN_SCHUR_HELPERS=1, and starneig_node_init's cores >= 3).  Measured at n = 20000 on
-    // the GPU box: the host AED time is the same with and without them (1.45 s: the refactored
-    // serial loops already run at the speed of the pipelined ones on that CPU) and so is the leg.
-    struct HelperSession {
-        bool on;
-        explicit HelperSession(int count) : on(count >= 2) { if (on) host::helper_session(true, count); }
-        ~HelperSession() { if (on) host::helper_session(false); }
-    } helper_session(helpers);
-
     SchurWorkspace &ws = g_sws[level];
     int const wmax = std::max({nw_conf, small_limit, 2 * WS_MAX});
     // Shift multiplicity: every shift pair of an AED drives `reuse` bulges of the following
@@ -1264,11 +1254,8 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // chains only add `gap` steps each, so the same shifts applied 8x cost ~1.3x the time of a
     // sweep and cut the number of sweeps at n = 20000 from 81 to 13 (measured: 7.0 s -> 5.4 s at
     // a 192-row AED window).
-    // The extra chain passes cost accuracy (orthogonality error ~ sqrt(chain passes): on slowly
-    // converging structured matrices -- all-ones Hessenberg, Toeplitz tridiagonal, n = 2600 --
-    // the residual is 260 / 440 / 780 u at multiplicity 1 / 4 / 8) and buy little where sweeps are
-    // short anyway, so the multiplicity grows with the size: 2 below n = 4000, 4 below 12000, 8
-    // above.  SN_SCHUR_REUSE=k overrides.
+    // The extra chain passes buy little where sweeps are short anyway, so the multiplicity grows with
+    // the size: 2 below n = 4000, 4 below 12000, 8 above.  SN_SCHUR_REUSE=k overrides.
     int const reuse_env = tuning().schur_reuse;
     // (a conf with many shifts -- the reference's 0.06 n -- fills the sweep by itself: the multiplicity is
     // capped so that a sweep carries ~450 bulges, what 8 x 53 give at the default sizes)
@@ -1293,6 +1280,16 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         thres = DBL_EPSILON * std::sqrt(h);
     } else if (thres == -3.0) thres = 0.0;      // LAPACK-style criteria
     else if (thres < 0.0) return STARNEIG_INVALID_CONFIGURATION;
+
+    // The helper team of the host window kernel (schur_host_team.h) for the duration of this reduction.
+    // Opened only now: for the session the calling thread is pinned to one core, and a thread that the
+    // runtime creates in the meantime would inherit that -- the workspace, its streams and the first
+    // synchronisation are behind us here.
+    struct HelperSession {
+        bool on;
+        explicit HelperSession(int count) : on(count >= 2) { if (on) host::helper_session(true, count); }
+        ~HelperSession() { if (on) host::helper_session(false); }
+    } helper_session(helpers);
 
     std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
     // Look-ahead: after a sweep the next one is started at once with the shifts at hand (stale
