@@ -3,6 +3,8 @@
 // extension (include/starneig_amd.h).  There is deliberately no CPU fallback:
 // without a usable gfx950 device starneig_node_init() aborts.
 #include "common.h"
+#include "tuning.h"
+#include <chrono>
 #include "schur_host.h"
 #include <algorithm>
 #include <cmath>
@@ -187,6 +189,8 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dA = nullptr, *dQ = nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[8]; tt[0] = now();
     SN_HIP_CHECK(hipMalloc((void **)&dA, bytes));
     SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
     if (g_node.pinning) {
@@ -195,17 +199,21 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     }
     SN_HIP_CHECK(hipMemset(dA, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
-    to_device(dA, ld, A, ldA, n);
-    to_device(dQ, ld, Q, ldQ, n);
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr)); tt[1] = now();
+    to_device(dA, ld, A, ldA, n); tt[2] = now();
+    to_device(dQ, ld, Q, ldQ, n); tt[3] = now();
 
     int rc = sn::hessenberg_device(nullptr, n, begin, end, panel_width, dA, ld, dQ, ld, nullptr);
-    SN_HIP_CHECK(hipStreamSynchronize(nullptr));
+    SN_HIP_CHECK(hipStreamSynchronize(nullptr)); tt[4] = now();
 
-    to_host(A, ldA, dA, ld, n);
-    to_host(Q, ldQ, dQ, ld, n);
+    to_host(A, ldA, dA, ld, n); tt[5] = now();
+    to_host(Q, ldQ, dQ, ld, n); tt[6] = now();
     if (g_node.pinning) { (void)hipHostUnregister(A); (void)hipHostUnregister(Q); }
     SN_HIP_CHECK(hipFree(dA));
-    SN_HIP_CHECK(hipFree(dQ));
+    SN_HIP_CHECK(hipFree(dQ)); tt[7] = now();
+    if (sn::tuning().schur_profile)
+        fprintf(stderr, "[api] Hessenberg n=%d: alloc+clear %.3f, upload A %.3f, upload Q %.3f, reduction %.3f, download A %.3f, download Q %.3f, free %.3f s\n",
+            n, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5], tt[7] - tt[6]);
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 }
 
