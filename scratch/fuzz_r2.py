@@ -7,7 +7,7 @@ import numpy as np, torch
 import starneig_amd as S, oracle as O
 from helpers import to_host, to_device
 torch.cuda.set_device(0); torch.zeros(1, device="cuda")
-S.node_init(1, 1, S.NO_MESSAGES)
+S.node_init(int(os.environ.get("SN_CORES", "16")), 1, S.NO_MESSAGES)
 bad = 0
 def flag(ok): 
     global bad
