@@ -95,6 +95,21 @@ SN_API void starneig_node_init(int cores, int gpus, starneig_flag_t flags)
     cpu_set_t mask;
     int avail = 1;
     if (sched_getaffinity(0, sizeof mask, &mask) == 0) avail = std::max(1, CPU_COUNT(&mask));
+    // a CPU-time quota of the control group (a container started with --cpus=k keeps the full mask): the
+    // helper threads of the window kernels spin, so threads beyond the quota would only get throttled
+    {
+        long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "max 100000" or "200000 100000"
+            char q[32] = {0};
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = -1; fclose(h); }
+        }
+        if (quota > 0 && period > 0) avail = std::max(1, std::min(avail, (int)(quota / period)));
+    }
     g_node.avail_cores = avail;
     g_node.cores = cores == STARNEIG_USE_ALL ? avail : std::max(1, std::min(cores, avail));
     if (gpus == 0) {
