@@ -109,7 +109,7 @@ struct SchurParams {            // resolved from starneig_schur_conf (negative =
     int aed_parallel_hard_limit = -1;   // AED windows up to this size use the sequential host kernel
     double threshold_b = -1.0;  // pencils: deflation threshold of B (right_threshold)
     double threshold_inf = -1.0;// pencils: infinite-eigenvalue threshold (inf_threshold)
-    int host_threads = 1;       // starneig_node_init's `cores`: >= 3 enables the helper threads of the host kernels
+    int host_threads = 1;       // starneig_node_init's `cores`: >= 6 gives the host window kernel its helper team (schur_host_team.h)
 };
 struct SchurStats {
     int sweeps = 0, aeds = 0, small_solves = 0, chase_launches = 0;
