@@ -172,15 +172,28 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     int const pivprev = R0 + j - 1, parp = (j - 1) & 1, par = j & 1;
     // scalars of column j-1 as published by gemv(j-1): P(piv-1, j-1) itself is overwritten
     // with beta by one block of THIS launch, so it must not be re-read here
+    // Everything this launch needs from memory that does not depend on anything computed here is
+    // requested in ONE round, in front of the first barrier: the scalars, row piv-1 of V with the slot
+    // sums, the gemv partials of this thread's row and its entry of column j (each of these used to be a
+    // round trip of its own on the column chain; the arithmetic and its order are unchanged).
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
+    constexpr int LPT = (MAXJ + CT - 1) / CT;
+    double vr_[LPT], ss_[LPT];
+    #pragma unroll
+    for (int q = 0; q < LPT; q++) {
+        int const l = tid + q * CT;
+        vr_[q] = l < j ? V[(size_t)l * ldp + pivprev] : 0.0;          // V(piv-1, l); = 1 for l = j-1
+        ss_[q] = l < j - 1 ? slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l) : 0.0;
+    }
+    double ysum_early = 0.0, pj_early = 0.0;
+    if (h == 0 && g < E) { ysum_early = split_sum(ypart, ldp, g, nsplit); pj_early = P[(size_t)j * ldp + g]; }
     __syncthreads();
     {
         double const scale = s_scal[0];
-        for (int l = tid; l < j; l += CT) {
-            double vr = V[(size_t)l * ldp + pivprev];          // V(piv-1, l); = 1 for l = j-1
-            s_vrow[l] = vr;
-            s_wv[l] = (l < j - 1)
-                ? vr + scale * slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l) : 0.0;
+        #pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            int const l = tid + q * CT;
+            if (l < j) { s_vrow[l] = vr_[q]; s_wv[l] = (l < j - 1) ? vr_[q] + scale * ss_[q] : 0.0; }
         }
     }
     __syncthreads();
@@ -215,11 +228,11 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
             double const tau = s_scal[1], beta = s_scal[2];
             #pragma unroll
             for (int q = 0; q < NG - 1; q++) { yacc += s_y[q][r]; pacc += s_pp[q][r]; }
-            double ysum = split_sum(ypart, ldp, g, nsplit);
+            double const ysum = ysum_early;
             double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
             Y[(size_t)(j - 1) * ldp + g] = ynew;
             pacc += ynew * s_vrow[j - 1];
-            pval = P[(size_t)j * ldp + g] - pacc;              // cpu.c:98-99
+            pval = pj_early - pacc;                            // cpu.c:98-99
             P[(size_t)j * ldp + g] = pval;
             // column j-1 of P is final: beta on the sub-diagonal, zeros below (cpu.c:153-154)
             if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
@@ -280,14 +293,27 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
     int const piv = R0 + j, par = j & 1;
     for (int l = tid; l < j; l += CTC)
         s_w[l] = slot_sum(acc + ACC_WSUM + par * NSLOT * MAXJ, l);
+    // requested in the same round as the slot sums (they depend on nothing computed here): this thread's
+    // entry of column j and the first four entries of its row of V -- same arithmetic, one round trip less
+    double const *vrow = V + g;
+    double pj_early = 0.0, x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+    bool const first4 = g < E && h + 3 * NGC < j;
+    if (h == 0 && g < E) pj_early = P[(size_t)j * ldp + g];
+    if (first4) {
+        x0 = vrow[(size_t)(h + 0 * NGC) * ldp]; x1 = vrow[(size_t)(h + 1 * NGC) * ldp];
+        x2 = vrow[(size_t)(h + 2 * NGC) * ldp]; x3 = vrow[(size_t)(h + 3 * NGC) * ldp];
+    }
     if (blockIdx.x == 0)      // wsum of the other parity: read by colC(j-1), re-used by colA(j+1)
         for (int l = tid; l < NSLOT * MAXJ; l += CTC)
             acc[ACC_WSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
     __syncthreads();
     double a = 0.0;
     if (g < E) {
-        double const *vrow = V + g;
         int l = h;
+        if (first4) {
+            a += x0 * s_w[l] + x1 * s_w[l + NGC] + x2 * s_w[l + 2 * NGC] + x3 * s_w[l + 3 * NGC];
+            l += 4 * NGC;
+        }
         for (; l + 3 * NGC < j; l += 4 * NGC)
             a += vrow[(size_t)(l + 0 * NGC) * ldp] * s_w[l] + vrow[(size_t)(l + 1 * NGC) * ldp] * s_w[l + NGC]
                + vrow[(size_t)(l + 2 * NGC) * ldp] * s_w[l + 2 * NGC] + vrow[(size_t)(l + 3 * NGC) * ldp] * s_w[l + 3 * NGC];
@@ -298,7 +324,7 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
     if (h == 0) {
         double below = 0.0;
         if (g < E) {
-            double pval = P[(size_t)j * ldp + g];
+            double pval = pj_early;
             if (j > 0) {                                                    // cpu.c:123-130
                 #pragma unroll
                 for (int q = 0; q < NGC - 1; q++) a += s_t[q][r];
