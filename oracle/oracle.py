@@ -62,6 +62,13 @@ def lib():
         L.oracle_hessenberg_triangular.argtypes = [C.c_int] + [dp, C.c_int] * 4
         L.oracle_hessenberg_triangular.restype = C.c_int
         L.oracle_lartg.argtypes = [C.c_double, C.c_double, dp, dp, dp]
+        ip = C.POINTER(C.c_int)
+        L.oracle_known_spectrum.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp]
+        L.oracle_place_blocks.argtypes = [C.c_int, dp, dp, dp, dp, C.c_int, dp, C.c_int]
+        L.oracle_householder_vector.argtypes = [C.c_int, dp]
+        L.oracle_decouple.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
+        L.oracle_known_eigenvalues_check.argtypes = [C.c_int] + [dp] * 6 + [C.c_double, C.c_double, dp, ip]
+        L.oracle_eigenvalues_check.argtypes = [C.c_int] + [dp] * 6 + [C.c_double, C.c_double, dp, ip]
         _LIB = L
     return _LIB
 
@@ -272,3 +279,103 @@ def lartg(f, g):
 def count_below_diagonal(T):
     n = T.shape[1]
     return int(np.count_nonzero(np.tril(T[:n, :n], -1)))
+
+
+# ---- the reference TEST DRIVER's Schur experiments (oracle/testdriver_oracle.c) -------------
+
+def _householder_apply(v, S, Zv=None):
+    """mul_QAZT(Q, S, Z) = Q S Z^T for Q = I - 2 v v^T, Z = I - 2 z z^T (test/common/init.c:543-550);
+    the reference forms Q and multiplies, this is the same product without the n^3."""
+    z = v if Zv is None else Zv
+    X = S - 2.0 * np.outer(v, v @ S)
+    return np.asfortranarray(X - 2.0 * np.outer(X @ z, z))
+
+
+def householder_matrix(n, ld=None):
+    """generate_random_householder (test/common/init.c:523-541): I - 2 v v^T, v from the LCG."""
+    ld = ld or ld_for(n)
+    v = np.zeros(n)
+    lib().oracle_householder_vector(n, _p(v))
+    Q = np.zeros((ld, n), order="F")
+    Q[:n] = np.eye(n) - 2.0 * np.outer(v, v)
+    return Q, v
+
+
+def known_pencil(n, generalized=False, seed=2019, complex_ratio=0.5, zero_ratio=0.01, inf_ratio=0.01,
+                 ld=None):
+    """`starneig-test --experiment schur --init known [--generalized]` before its Hessenberg
+    step (test/schur/experiment.c:295-353): returns the dense A (and B), and the prescribed
+    eigenvalues (real, imag, beta) as the reference's extract_eigenvalues reads them off the
+    generating Schur form."""
+    ld = ld or ld_for(n)
+    L = lib()
+    L.oracle_init_prand(seed)
+    S = np.zeros((ld, n), order="F")
+    L.oracle_fill_random_uptriag(n, _p(S), ld)
+    T = None
+    if generalized:
+        T = identity(n, ld)
+    real, imag, beta = np.zeros(n), np.zeros(n), np.zeros(n)
+    L.oracle_known_spectrum(n, int(generalized), complex_ratio, zero_ratio, inf_ratio,
+                            _p(real), _p(imag), _p(beta))
+    L.oracle_place_blocks(n, _p(real), _p(imag), _p(beta), _p(S), ld,
+                          _p(T) if generalized else None, ld)
+    if generalized:
+        kr, ki, kb = gep_extract_eigenvalues(S, T)
+    else:
+        kr, ki = extract_eigenvalues(S)
+        kb = np.ones(n)
+    q = np.zeros(n)
+    L.oracle_householder_vector(n, _p(q))
+    A = np.zeros((ld, n), order="F")
+    if generalized:
+        z = np.zeros(n)
+        L.oracle_householder_vector(n, _p(z))
+        A[:n] = _householder_apply(q, S[:n], z)
+        B = np.zeros((ld, n), order="F")
+        B[:n] = _householder_apply(q, T[:n], z)
+        return A, B, kr, ki, kb
+    A[:n] = _householder_apply(q, S[:n])
+    return A, None, kr, ki, kb
+
+
+def schur_random_input(n, generalized=False, decouple=0, set_to_inf=0, seed=2019, ld=None):
+    """`starneig-test --experiment schur [--generalized] [--decouple k] [--set-to-inf k]`, the
+    default `random` initializer (test/schur/experiment.c:181-214): random upper Hessenberg H,
+    Q a random Householder matrix, (B random upper triangular, Z a second Householder matrix),
+    then the cuts.  Returns H, Q, B, Z (B, Z None in the standard case)."""
+    ld = ld or ld_for(n)
+    L = lib()
+    L.oracle_init_prand(seed)
+    H = np.zeros((ld, n), order="F")
+    L.oracle_fill_random_hessenberg(n, _p(H), ld)
+    Q, _ = householder_matrix(n, ld)
+    B = Z = None
+    if generalized:
+        B = np.zeros((ld, n), order="F")
+        L.oracle_fill_random_uptriag(n, _p(B), ld)
+        Z, _ = householder_matrix(n, ld)
+    if decouple > 0 or set_to_inf > 0:
+        L.oracle_decouple(n, decouple, set_to_inf, _p(H), ld, _p(B) if generalized else None, ld)
+    return H, Q, B, Z
+
+
+def _hook(fn, a, b, warn, fail):
+    n = len(a[0])
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (*a, *b)]
+    out = np.zeros(3)
+    counts = (C.c_int * 2)()
+    fn(n, *[_p(x) for x in arrs], float(warn), float(fail), _p(out), counts)
+    return {"mean_u": out[0], "min_u": out[1], "max_u": out[2], "warnings": counts[0], "failures": counts[1]}
+
+
+def known_eigenvalues_check(computed, known, warn=1e4, fail=1e6):
+    """The reference's `known-eigenvalues` hook with its default thresholds
+    (test/common/hooks.c:1071-1072,1178-1296). computed / known = (real, imag, beta)."""
+    return _hook(lib().oracle_known_eigenvalues_check, computed, known, warn, fail)
+
+
+def eigenvalues_check(extracted, returned, warn=1e3, fail=1e4):
+    """The reference's `eigenvalues` hook (test/common/hooks.c:787-788,891-991): eigenvalues read
+    off the diagonal blocks of the result against those the solver returned, by position."""
+    return _hook(lib().oracle_eigenvalues_check, extracted, returned, warn, fail)

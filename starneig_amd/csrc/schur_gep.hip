@@ -367,6 +367,7 @@ struct GepDriver {
     int n; double *A; int ldA; double *B; int ldB; double *Q; int ldQ; double *Z; int ldZ;
     GepWorkspace &ws;
     SchurStats st;
+    double thres_b = 0.0;       // B-side threshold of the host window kernels (0: LAPACK's BTOL per window)
 
     // X <- op applied in place through the scratch panel for windows wider than one GEMM tile
     void left_update(double *X, int ld, int lo, int w, double const *dU, int ldu)
@@ -454,7 +455,7 @@ struct GepDriver {
         for (int j = 0; j < w; j++)
             for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
         std::vector<double> ar(w), ai(w), be(w);
-        int info = host::gep_small_schur(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, w, ar.data(), ai.data(), be.data());
+        int info = host::gep_small_schur(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, w, ar.data(), ai.data(), be.data(), thres_b);
         if (info != 0) return info;
         upload_windows(lo, w);
         apply_transform(lo, w, ws.dQl, ws.dZl, w);
@@ -711,6 +712,20 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         thres_inf = DBL_EPSILON * std::sqrt(h);
     } else if (thres_inf <= 0.0) return STARNEIG_INVALID_CONFIGURATION;
 
+    // B-side threshold of the host window kernels (conf->right_threshold, schur/core.c:2438-2449):
+    // norm-stable = u*||B||_F, a positive value as given; default and LAPACK (-3) = LAPACK dhgeqz's
+    // BTOL of the window at hand (<= 0 tells the kernels to compute it)
+    double thres_b = prm.threshold_b;
+    if (thres_b == -2.0) {
+        double h = 0.0;
+        sumsq_ordered(s, n, n, dB, ldB, ws.dTmp, ws.dAcc);
+        SN_HIP_CHECK(hipMemcpyAsync(&h, ws.dAcc, 8, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        thres_b = DBL_EPSILON * std::sqrt(h);
+    } else if (thres_b == -1.0 || thres_b == -3.0) thres_b = 0.0;
+    else if (thres_b <= 0.0) return STARNEIG_INVALID_CONFIGURATION;
+    d.thres_b = thres_b;
+
     std::vector<double> sr(8 * wmax), si(8 * wmax), spike(wmax);
     int rc = STARNEIG_SUCCESS;
     int ihi = n, iter = 0, stagnation = 0;
@@ -755,7 +770,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         double t_aed0 = wall();
         int const ldh = GepDriver::host_ld(nw);
         host::AedResult ar = host::gep_aed_window(nw, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, sub, thres,
-            spike.data(), sr.data(), si.data());
+            spike.data(), sr.data(), si.data(), thres_b);
         d.st.aed_host_s += wall() - t_aed0;
         d.st.aeds++;
         if (ar.failed) { rc = STARNEIG_DID_NOT_CONVERGE; break; }

@@ -30,13 +30,16 @@ void gep_push_inf_window(int w, double *A, int lda, double *B, int ldb, double *
     double *Z, int ldz, int from, int to, int deflate);
 void gep_push_inf_down_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int from, int deflate);
+// thres_b: magnitude below which an entry of B is negligible (conf->right_threshold; LAPACK dhgeqz's
+// BTOL): > 0 that value, otherwise max(safmin, u * ||B||_F) of the pencil at hand
 int gep_small_schur(int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
-    double *Z, int ldz, int nq, double *ar, double *ai, double *be);
+    double *Z, int ldz, int nq, double *ar, double *ai, double *be, double thres_b = -1.0);
 void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int ldb,
     double *Q, int ldq, double *Z, int ldz, int nq);
 int gep_move_block_up(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int nq, int from, int to);
 AedResult gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
-    double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si);
+    double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si,
+    double thres_b = -1.0);
 
 }} // namespace sn::host

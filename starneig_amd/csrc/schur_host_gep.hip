@@ -36,7 +36,7 @@ inline double sgn(double a, double b) { return b >= 0.0 ? std::fabs(a) : -std::f
 inline double norm2(double a, double b)
 {
     double const x = std::fabs(a), y = std::fabs(b), hi = std::max(x, y), lo = std::min(x, y);
-    if (hi < 1e150 && (lo > 1e-150 || lo == 0.0)) return std::sqrt(x * x + y * y);
+    if (hi < 1e150 && hi > 1e-150 && (lo > 1e-150 || lo == 0.0)) return std::sqrt(x * x + y * y);
     return std::hypot(a, b);
 }
 
@@ -376,14 +376,19 @@ void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_,
 // U1^T A U2 quasi-triangular, U1^T B U2 triangular.  Q and Z have nq rows.  Returns 0 or the
 // (1-based) row where the iteration limit was hit.
 int gep_small_schur(int n, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
-    double *Z_, int ldz, int nq, double *ar, double *ai, double *be)
+    double *Z_, int ldz, int nq, double *ar, double *ai, double *be, double thres_b)
 {
     Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
     const double ulp = DBL_EPSILON, safmin = DBL_MIN;
     if (n == 0) return 0;
-    double bn = 0.0;
-    for (int j = 0; j < n; j++) for (int i = 0; i <= j; i++) bn = std::hypot(bn, B(i, j));
-    const double btol = std::max(safmin, ulp * bn);
+    // B-side threshold (conf->right_threshold, schur/core.c:2438-2449): an explicit or norm-stable
+    // value from the caller, otherwise LAPACK dhgeqz's BTOL for the pencil at hand
+    double btol = thres_b;
+    if (!(btol > 0.0)) {
+        double bn = 0.0;
+        for (int j = 0; j < n; j++) for (int i = 0; i <= j; i++) bn = std::hypot(bn, B(i, j));
+        btol = std::max(safmin, ulp * bn);
+    }
     for (int j = 0; j < n; j++) {               // clean below the (sub)diagonal
         for (int i = j + 2; i < n; i++) A(i, j) = 0.0;
         for (int i = j + 1; i < n; i++) B(i, j) = 0.0;
@@ -405,8 +410,22 @@ int gep_small_schur(int n, double *A_, int lda, double *B_, int ldb, double *Q_,
             }
             ilast--; iiter = 0; continue;
         }
-        // numerically singular B inside the block: perturb by u*||B|| (see the file header)
-        for (int j = ifirst; j <= ilast; j++)
+        // a negligible diagonal entry of B at the bottom of the block: an infinite eigenvalue, split off
+        // as LAPACK dhgeqz does (B(ilast,ilast) = 0 exactly, a column rotation annihilates
+        // A(ilast,ilast-1)); this is where conf->right_threshold decides
+        if (std::fabs(B(ilast, ilast)) < btol) {
+            B(ilast, ilast) = 0.0;
+            double const x = A(ilast, ilast - 1), y = A(ilast, ilast), r = norm2(x, y);
+            double c = 1.0, s = 0.0;
+            if (r != 0.0) { c = y / r; s = -x / r; }     // [x y] G = [0 r]
+            rot_cols(A, ilast - 1, ilast, 0, ilast + 1, c, s);
+            rot_cols(B, ilast - 1, ilast, 0, ilast, c, s);
+            rot_cols(Z, ilast - 1, ilast, 0, nq, c, s);
+            A(ilast, ilast - 1) = 0.0;
+            ilast--; iiter = 0; continue;
+        }
+        // numerically singular B elsewhere inside the block: perturb to the threshold (see the file header)
+        for (int j = ifirst; j < ilast; j++)
             if (std::fabs(B(j, j)) < btol) B(j, j) = (B(j, j) < 0.0) ? -btol : btol;
         if (ifirst == ilast - 1) {              // 2x2 block
             int kind = gep_standardise_2x2(n, A, B, Q, Z, nq, ifirst);
@@ -720,7 +739,7 @@ int gep_move_block_up(int nw, double *A_, int lda, double *B_, int ldb, double *
 // top of the window.  On return (S,T) = [HT (ns x ns) | *; 0 | Schur (nd x nd)], Q/Z the accumulated
 // transformations, spike[0] the new coupling entry, shifts as complex numbers alpha/beta.
 AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq,
-    double *Z_, int ldz, double sub, double thres, double *spike, double *sr, double *si)
+    double *Z_, int ldz, double sub, double thres, double *spike, double *sr, double *si, double thres_b)
 {
     AedResult res{0, 0, 0};
     Mat A{A_, lda}, B{B_, ldb}, Q{Q_, ldq}, Z{Z_, ldz};
@@ -730,7 +749,7 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
     static double t_schur = 0, t_reorder = 0, t_rest = 0; static int calls = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double const t0 = prof ? now() : 0.0;
-    int info = gep_small_schur(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, ar.data(), ai.data(), be.data());
+    int info = gep_small_schur(nw, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, nw, ar.data(), ai.data(), be.data(), thres_b);
     if (info != 0) { res.failed = 1; return res; }
     double const t1 = prof ? now() : 0.0;
     // deflation scan from the bottom; undeflatable blocks are moved to the top of the window

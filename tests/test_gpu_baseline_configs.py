@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from helpers import WARN_U, to_host
+from helpers import WARN_U, to_host, torch_check
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,12 @@ def test_config3_hessenberg_schur_n20000(node):
     # 1.5 x the reference's published Hessenberg residuals at n = 4000 (15 u / 11 u); no allowance
     # for the five times larger n
     assert chk["residual_u"] < 1.5 * 15 and chk["orthogonality_u"] < 1.5 * 11
+    # the same two numbers from torch.matmul in fp64 (independent of the library's check kernels)
+    res_t, orth_t = torch_check(tQ, tH, tA0, n)
+    print(f"Hessenberg n={n}: library {chk['residual_u']:.2f} / {chk['orthogonality_u']:.2f} u, "
+          f"torch {res_t:.2f} / {orth_t:.2f} u")
+    assert abs(res_t - chk["residual_u"]) <= 0.2 * res_t and abs(orth_t - chk["orthogonality_u"]) <= 0.2 * orth_t
+    assert res_t < 1.5 * 15 and orth_t < 1.5 * 11
     trace = float(torch.diagonal(tA0[:, :n]).sum())
     assert abs(float(torch.diagonal(tH[:, :n]).sum()) - trace) <= 1e-9 * n
     rc, real, imag, st = node.schur_device(tH, tQ, n=n)
@@ -56,6 +62,11 @@ def test_config3_hessenberg_schur_n20000(node):
     assert rc == 0
     assert chk["residual_u"] < WARN_U and chk["orthogonality_u"] < WARN_U
     assert chk["below_subdiagonal"] == 0
+    res_t, orth_t = torch_check(tQ, tH, tA0, n)
+    print(f"Schur n={n}: library {chk['residual_u']:.2f} / {chk['orthogonality_u']:.2f} u, "
+          f"torch {res_t:.2f} / {orth_t:.2f} u")
+    assert abs(res_t - chk["residual_u"]) <= 0.2 * res_t and abs(orth_t - chk["orthogonality_u"]) <= 0.2 * orth_t
+    assert res_t < WARN_U and orth_t < WARN_U
     assert schur_form_ok_device(tH, n)
     assert abs(real.sum() - trace) <= 1e-9 * n
     # eigenvalues returned == eigenvalues of the diagonal blocks; pairs adjacent, +imag first

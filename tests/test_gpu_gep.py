@@ -277,3 +277,42 @@ def test_qz_infinite_eigenvalues_device_n3000(node):
     assert ca["below_subdiagonal"] == 0 and cb["below_subdiagonal"] == 0
     assert int((be == 0.0).sum()) == len(zeros)
     assert O.check_gep_schur_form(to_host(tH), to_host(tR)) == 0
+
+
+@pytest.mark.parametrize("n", [150, 700])
+def test_right_threshold_decides_b_side_deflation(node, n):
+    """conf->right_threshold (expert.h:337-349; thres_b of schur/core.c:2438-2449): the magnitude
+    below which an entry of R is negligible.  A diagonal entry d = 1e-9 at the bottom of R is far
+    above every default threshold (u ||R||_F ~ 1e-15): with the defaults the pencil has n finite
+    eigenvalues, one of them ~1e9; with right_threshold = 1e-6 the entry is set to zero and split
+    off as an infinite eigenvalue (beta = 0 exactly), at a backward error of d / ||R||; the
+    norm-stable setting (-2) and the LAPACK setting (-3) behave like the default here.
+    n = 150: the small-block kernel; n = 700: the AED window kernel of the device path."""
+    H0, R0 = O.random_pencil_wellcond(n)
+    d = 1e-9
+    R0[n - 1, n - 1] = d
+    counts = {}
+    for label, thr in (("default", -1.0), ("norm_stable", -2.0), ("lapack", -3.0), ("explicit", 1e-6)):
+        conf = node.schur_init_conf()
+        conf.right_threshold = thr
+        S, T, Q, Z, ar, ai, be = run_host(node, H0, R0, conf)
+        assert O.check_gep_schur_form(S, T) == 0
+        assert O.pencil_residual_u(Q, S, Z, H0) < WARN_U
+        assert O.orthogonality_u(Q) < WARN_U and O.orthogonality_u(Z) < WARN_U
+        resb = O.pencil_residual_u(Q, T, Z, R0)
+        counts[label] = int((be == 0.0).sum())
+        if label == "explicit":
+            # the dropped entry IS the backward error: d / ||R||_F, nothing more
+            assert resb * U <= 1.5 * d / np.linalg.norm(R0[:n]) + WARN_U * U, resb
+            i = int(np.nonzero(be == 0.0)[0][0])
+            assert T[i, i] == 0.0 and ai[i] == 0.0 and ar[i] == S[i, i]
+        else:
+            assert resb < WARN_U
+            assert np.abs((ar + 1j * ai) / be).max() > 1e7      # the huge finite eigenvalue
+    assert counts == {"default": 0, "norm_stable": 0, "lapack": 0, "explicit": 1}, counts
+    conf = node.schur_init_conf()
+    conf.right_threshold = -5.0
+    H, R = H0.copy(order="F"), R0.copy(order="F")
+    Q, Z = O.identity(n, ld=H.shape[0]), O.identity(n, ld=H.shape[0])
+    assert node.GEP_SM_Schur_expert(conf, n, H, H.shape[0], R, R.shape[0], Q, Q.shape[0], Z, Z.shape[0],
+                                    None, None, None) == node.INVALID_CONFIGURATION

@@ -39,17 +39,38 @@ def check_reordered(A0, S, Q, real, imag, sel_in_eigs, sel_out, n):
         rest.pop(j)
 
 
+def threshold_in_a_gap(ev0, frac):
+    """a real-part threshold near the (1 - frac) quantile that sits in the middle of the widest gap
+    between neighbouring real parts there, so that two solvers agree on which eigenvalues lie
+    above it"""
+    re = np.sort(np.unique(np.round(ev0.real, 12)))
+    c = int(len(re) * (1.0 - frac))
+    lo, hi = max(1, c - 8), min(len(re) - 1, c + 8)
+    j = lo + int(np.argmax(re[lo:hi] - re[lo - 1:hi - 1]))
+    return 0.5 * (re[j - 1] + re[j])
+
+
 @pytest.mark.parametrize("n,frac", [(50, 0.5), (300, 0.3), (1000, 0.5), (2000, 0.5)])
 def test_select_and_reorder_after_schur(node, n, frac):
+    """The selection is judged against an INDEPENDENT eigen-solve: the eigenvalues of the leading
+    k x k block of the reordered form (numpy / LAPACK on that block) must be those members of
+    numpy.linalg.eigvals(A0) that satisfy the predicate -- same count, matched within 1e4 u (the
+    reference's `eigenvalues` fail threshold, test/common/hooks.c:787)."""
     A0, S, Q, real, imag = schur_of_lcg(node, n)
-    thr = np.quantile(real, 1.0 - frac)
+    ev0 = np.linalg.eigvals(A0[:n])
+    thr = threshold_in_a_gap(ev0, frac)
     rc, sel, cnt = node.SEP_SM_Select(n, S, S.shape[0], lambda re, im: re > thr)
     assert rc == 0 and cnt > 0
+    members = ev0[ev0.real > thr]
+    assert cnt == len(members)
     eigs = [real[i] + 1j * imag[i] for i in range(n) if sel[i]]
     assert len(eigs) == cnt
     r2 = np.zeros(n); i2 = np.zeros(n)
     assert node.SEP_SM_ReorderSchur(n, sel, S, S.shape[0], Q, Q.shape[0], r2, i2) == 0
     check_reordered(A0, S, Q, r2, i2, eigs, sel, n)
+    lead = np.linalg.eigvals(S[:cnt, :cnt])
+    assert O.match_eigenvalues(lead, members) < 1e4
+    assert O.match_eigenvalues(np.linalg.eigvals(S[cnt:n, cnt:n]), ev0[ev0.real <= thr]) < 1e4
 
 
 def test_reduce_with_predicate_runs_the_example_chain(node):
@@ -65,6 +86,9 @@ def test_reduce_with_predicate_runs_the_example_chain(node):
     assert O.residual_u(Q, A, A0) < WARN_U and O.orthogonality_u(Q) < WARN_U
     assert np.all(real[:cnt] > 0.0) and np.all(real[cnt:] <= 0.0)
     assert np.array_equal(sel, (np.arange(n) < cnt).astype(np.int32))
+    ev0 = np.linalg.eigvals(A0[:n])
+    assert cnt == int((ev0.real > 0.0).sum())
+    assert O.match_eigenvalues(np.linalg.eigvals(A[:cnt, :cnt]), ev0[ev0.real > 0.0]) < 1e4
 
 
 @pytest.mark.parametrize("which", ["none", "all", "leading", "last_one", "half_of_a_pair"])
