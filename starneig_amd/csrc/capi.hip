@@ -208,10 +208,6 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     double tt[8]; tt[0] = now();
     SN_HIP_CHECK(hipMalloc((void **)&dA, bytes));
     SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
-    if (g_node.pinning) {
-        (void)hipHostRegister(A, (size_t)ldA * n * sizeof(double), hipHostRegisterDefault);
-        (void)hipHostRegister(Q, (size_t)ldQ * n * sizeof(double), hipHostRegisterDefault);
-    }
     SN_HIP_CHECK(hipMemset(dA, 0, bytes));
     SN_HIP_CHECK(hipMemset(dQ, 0, bytes));
     SN_HIP_CHECK(hipStreamSynchronize(nullptr)); tt[1] = now();
@@ -223,7 +219,6 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
 
     to_host(A, ldA, dA, ld, n); tt[5] = now();
     to_host(Q, ldQ, dQ, ld, n); tt[6] = now();
-    if (g_node.pinning) { (void)hipHostUnregister(A); (void)hipHostUnregister(Q); }
     SN_HIP_CHECK(hipFree(dA));
     SN_HIP_CHECK(hipFree(dQ)); tt[7] = now();
     if (sn::tuning().schur_profile)

@@ -57,6 +57,11 @@ void gemm_tile(int m, int n, int k, double alpha,
     // interior tiles: straight 16-byte loads, no per-element bounds tests
     bool const tile_full = (r0 + BM <= m) && (c0 + BN <= n);
 
+    // Boundary tiles / the partial last k-tile: the loads are UNCONDITIONAL from clamped addresses
+    // (always inside the operands) and the out-of-range entries are replaced by zeros where the
+    // tile goes to LDS.  (Predicated loads -- `v = 0; if (in range) v = load` -- made the compiler
+    // wait for every earlier load before each zero-initialisation: sixteen memory latencies per
+    // k-tile in a row, and the boundary tiles ended the launch late.)
     auto load_tiles = [&](int k0) {
         if (tile_full && k0 + KT <= k) {
             #pragma unroll
@@ -77,7 +82,7 @@ void gemm_tile(int m, int n, int k, double alpha,
                            v = *reinterpret_cast<d2u const *>(B + (size_t)(c0 + mn) * ldb + k0 + kk); }
                 else     { int mn = (e % (BN / 2)) * 2, kk = e / (BN / 2);
                            v = *reinterpret_cast<d2u const *>(B + (size_t)(k0 + kk) * ldb + c0 + mn); }
-                creg[2 * s] = v.x * opscale; creg[2 * s + 1] = v.y * opscale;
+                creg[2 * s] = v.x; creg[2 * s + 1] = v.y;
             }
             return;
         }
@@ -89,11 +94,8 @@ void gemm_tile(int m, int n, int k, double alpha,
                 int mn, kk;
                 if (TA) { kk = (e % (KT / 2)) * 2 + h; mn = e / (KT / 2); }
                 else    { mn = (e % (BM / 2)) * 2 + h; kk = e / (BM / 2); }
-                int r = r0 + mn, kg = k0 + kk;
-                double v = 0.0;
-                if (r < m && kg < k)
-                    v = TA ? A[(size_t)r * lda + kg] : A[(size_t)kg * lda + r];
-                rreg[2 * s + h] = v;
+                int r = min(r0 + mn, m - 1), kg = min(k0 + kk, k - 1);
+                rreg[2 * s + h] = TA ? A[(size_t)r * lda + kg] : A[(size_t)kg * lda + r];
             }
         }
         #pragma unroll
@@ -104,31 +106,47 @@ void gemm_tile(int m, int n, int k, double alpha,
                 int mn, kk;
                 if (!TB) { kk = (e % (KT / 2)) * 2 + h; mn = e / (KT / 2); }
                 else     { mn = (e % (BN / 2)) * 2 + h; kk = e / (BN / 2); }
-                int c = c0 + mn, kg = k0 + kk;
-                double v = 0.0;
-                if (c < n && kg < k)
-                    v = TB ? B[(size_t)kg * ldb + c] : B[(size_t)c * ldb + kg];
-                creg[2 * s + h] = v * opscale;
+                int c = min(c0 + mn, n - 1), kg = min(k0 + kk, k - 1);
+                creg[2 * s + h] = TB ? B[(size_t)kg * ldb + c] : B[(size_t)c * ldb + kg];
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    // k0: the k-offset of the tile held in rreg / creg
+    auto store_tiles = [&](int buf, int k0) {
         double *dR = smem + buf * BUF_ELEMS, *dC = dR + Cfg::R_ELEMS;
+        bool const full = tile_full && k0 + KT <= k;
         #pragma unroll
         for (int s = 0; s < Cfg::R_LOADS / 2; s++) {
             int e = tid + s * 256;
             double *d;
-            if (TA) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2); d = dR + mn * Cfg::LDR + kk; }
-            else    { int mn = (e % (BM / 2)) * 2, kk = e / (BM / 2); d = dR + kk * Cfg::LDR + mn; }
-            *reinterpret_cast<d2 *>(d) = (d2){rreg[2 * s], rreg[2 * s + 1]};
+            int mn, kk;
+            if (TA) { kk = (e % (KT / 2)) * 2; mn = e / (KT / 2); d = dR + mn * Cfg::LDR + kk; }
+            else    { mn = (e % (BM / 2)) * 2; kk = e / (BM / 2); d = dR + kk * Cfg::LDR + mn; }
+            double x = rreg[2 * s], y = rreg[2 * s + 1];
+            if (!full) {
+                bool const in0 = (r0 + mn < m) && (k0 + kk < k);
+                bool const in1 = TA ? ((r0 + mn < m) && (k0 + kk + 1 < k)) : ((r0 + mn + 1 < m) && (k0 + kk < k));
+                x = in0 ? x : 0.0; y = in1 ? y : 0.0;
+            }
+            *reinterpret_cast<d2 *>(d) = (d2){x, y};
         }
         #pragma unroll
         for (int s = 0; s < Cfg::C_LOADS / 2; s++) {
             int e = tid + s * 256;
             double *d;
-            if (!TB) { int kk = (e % (KT / 2)) * 2, mn = e / (KT / 2); d = dC + mn * Cfg::LDC + kk; }
-            else     { int mn = (e % (BN / 2)) * 2, kk = e / (BN / 2); d = dC + kk * Cfg::LDC + mn; }
-            *reinterpret_cast<d2 *>(d) = (d2){creg[2 * s], creg[2 * s + 1]};
+            int mn, kk;
+            if (!TB) { kk = (e % (KT / 2)) * 2; mn = e / (KT / 2); d = dC + mn * Cfg::LDC + kk; }
+            else     { mn = (e % (BN / 2)) * 2; kk = e / (BN / 2); d = dC + kk * Cfg::LDC + mn; }
+            // (the sign of the column operand is applied HERE, not where the tile is loaded: a use of
+            // the loaded registers before the MFMA block makes the compiler wait for the global loads
+            // of the next k-tile before it issues this k-tile's MFMAs)
+            double x = creg[2 * s] * opscale, y = creg[2 * s + 1] * opscale;
+            if (!full) {
+                bool const in0 = (c0 + mn < n) && (k0 + kk < k);
+                bool const in1 = !TB ? ((c0 + mn < n) && (k0 + kk + 1 < k)) : ((c0 + mn + 1 < n) && (k0 + kk < k));
+                x = in0 ? x : 0.0; y = in1 ? y : 0.0;
+            }
+            *reinterpret_cast<d2 *>(d) = (d2){x, y};
         }
     };
 
@@ -163,7 +181,7 @@ void gemm_tile(int m, int n, int k, double alpha,
             }
     }
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; kt++) {
@@ -202,7 +220,7 @@ void gemm_tile(int m, int n, int k, double alpha,
                 }
         }
 
-        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * KT);
         __syncthreads();
     }
 

@@ -1224,7 +1224,10 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
                                                                  : (prm.host_threads >= 6 ? 5 : 0)) : 0;
     // The balance moves with n (the sweeps get longer, the window kernel does not): 0.21 s at 192 / 128
     // against 0.31 s at 256 / 160 for n = 4000, 0.46 s against 0.58 s for n = 8000.
-    int const nw_cap = std::min(helpers >= 2 ? 288 : 192, (136 + (int)(0.006 * n) + 8) / 16 * 16);
+    // (a replica that carries a row block of Q -- the sharded Schur leg -- must choose the same window
+    // as its peers whatever cores each of them was granted: there the cap does not depend on the helpers)
+    bool const replica = q_rows >= 0 && q_rows < n;
+    int const nw_cap = std::min((helpers >= 2 && !replica) ? 288 : 192, (136 + (int)(0.006 * n) + 8) / 16 * 16);
     nw_default = std::min(nw_default, nw_cap);
     ns_default = std::min(ns_default, nw_cap * 5 / 8);
     // AED windows above the hard limit (process_args.c:372-398, default 300) are reduced by the

@@ -195,6 +195,43 @@ inline void pencil2_sum_prod(double a11, double a12, double a21, double a22,
     prod = (a11 * a22 - a12 * a21) / den;
 }
 
+// Eigenvalues of the 2x2 pencil (a, b), b upper triangular with b11, b22 != 0, computed as
+// shift + (pp +- sqrt(pp^2 + qq)) with shift = the smaller of a11/b11, a22/b22 (the published
+// algorithm of LAPACK dlag2, which the reference calls: common/math.c:148-176).  The quadratic
+// formula on (sum, prod) loses the difference of two close eigenvalues to cancellation -- a real
+// pair -4423.50 / -4424.03 came out as a "complex" pair with zero imaginary part, an error of 1e-4.
+// Returns true for a real pair: lr[0] the eigenvalue of larger magnitude, lr[1] the smaller one;
+// false for a complex pair lr[0] +- i lr[1] (lr[1] > 0).
+inline bool pencil2_eigenvalues(double a11, double a12, double a21, double a22,
+    double b11, double b12, double b22, double lr[2])
+{
+    double const binv11 = 1.0 / b11, binv22 = 1.0 / b22;
+    double const s1 = a11 * binv11, s2 = a22 * binv22;
+    double const ss = a21 * (binv11 * binv22);
+    double as12, pp, shift;
+    if (std::fabs(s1) <= std::fabs(s2)) {
+        as12 = a12 - s1 * b12;
+        double const as22 = a22 - s1 * b22, abi22 = as22 * binv22 - ss * b12;
+        pp = 0.5 * abi22; shift = s1;
+    } else {
+        as12 = a12 - s2 * b12;
+        double const as11 = a11 - s2 * b11, abi22 = -ss * b12;
+        pp = 0.5 * (as11 * binv11 + abi22); shift = s2;
+    }
+    double const qq = ss * as12, discr = pp * pp + qq;
+    if (discr >= 0.0) {
+        double const r = std::sqrt(discr), sr = (pp >= 0.0) ? r : -r;
+        double wbig = shift + (pp + sr), wsmall = shift + (pp - sr);
+        if (std::fabs(wbig) < std::fabs(wsmall)) std::swap(wbig, wsmall);
+        if (0.5 * std::fabs(wbig) > std::max(std::fabs(wsmall), DBL_MIN))
+            wsmall = ((a11 * a22 - a12 * a21) * (binv11 * binv22)) / wbig;
+        lr[0] = wbig; lr[1] = wsmall;
+        return true;
+    }
+    lr[0] = shift + pp; lr[1] = std::sqrt(-discr);
+    return false;
+}
+
 } // namespace
 
 // Standardises the 2x2 diagonal block at p of the pencil (A,B) (B upper triangular):
@@ -224,16 +261,11 @@ static int gep_standardise_2x2(int n, Mat A, Mat B, Mat Q, Mat Z, int nq, int p)
             if (pass > 8) break;
         }
         prev = std::fabs(a21);
-        double sum, prod;
-        pencil2_sum_prod(a11, a12, a21, a22, b11, b12, b22, sum, prod);
-        double disc = 0.25 * sum * sum - prod;
-        if (!(disc >= 0.0)) break;
-        // real pair: deflate the eigenvalue of SMALLER magnitude (computed without cancellation
-        // as prod / larger root).  With a nearly singular B block the other one is ~1/u and
-        // A - lam B would be dominated by lam B, losing the null vector
-        double rt = std::sqrt(disc);
-        double l_big = 0.5 * sum + (sum >= 0.0 ? rt : -rt);
-        double lam = (l_big != 0.0) ? prod / l_big : 0.0;
+        double lr[2];
+        if (!pencil2_eigenvalues(a11, a12, a21, a22, b11, b12, b22, lr)) break;
+        // real pair: deflate the eigenvalue of SMALLER magnitude.  With a nearly singular B block
+        // the other one is ~1/u and A - lam B would be dominated by lam B, losing the null vector
+        double const lam = lr[1];
         // right null vector x of M = A22 - lam B22
         double m00 = a11 - lam * b11, m01 = a12 - lam * b12, m10 = a21, m11 = a22 - lam * b22;
         double x0, x1;
@@ -361,12 +393,14 @@ void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_,
     Mat S{const_cast<double *>(S_), lds}, T{const_cast<double *>(T_), ldt};
     for (int i = 0; i < n; i++) {
         if (i + 1 < n && S(i + 1, i) != 0.0) {
-            double sum, prod;
-            pencil2_sum_prod(S(i, i), S(i, i + 1), S(i + 1, i), S(i + 1, i + 1),
-                T(i, i), T(i, i + 1), T(i + 1, i + 1), sum, prod);
-            double disc = prod - 0.25 * sum * sum;
-            double wi = disc > 0.0 ? std::sqrt(disc) : 0.0;
-            ar[i] = ar[i + 1] = 0.5 * sum; ai[i] = wi; ai[i + 1] = -wi; be[i] = be[i + 1] = 1.0;
+            double lr[2];
+            if (pencil2_eigenvalues(S(i, i), S(i, i + 1), S(i + 1, i), S(i + 1, i + 1),
+                    T(i, i), T(i, i + 1), T(i + 1, i + 1), lr)) {
+                // (a block that the standardisation could not split although its eigenvalues are
+                // real -- they differ by rounding: report them as they are)
+                ar[i] = lr[0]; ar[i + 1] = lr[1]; ai[i] = ai[i + 1] = 0.0;
+            } else { ar[i] = ar[i + 1] = lr[0]; ai[i] = lr[1]; ai[i + 1] = -lr[1]; }
+            be[i] = be[i + 1] = 1.0;
             i++;
         } else { ar[i] = S(i, i); ai[i] = 0.0; be[i] = T(i, i); }
     }

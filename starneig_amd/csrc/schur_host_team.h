@@ -293,6 +293,11 @@ struct Team {
     std::thread th[MAXH];
     std::mutex mu;
     std::condition_variable cv;
+    // helpers that found no work for ~IDLE_SPINS pauses (the caller is blocked on the GPU: a sweep takes
+    // tens of milliseconds) stop spinning and wait here until the next publish()
+    static constexpr unsigned IDLE_SPINS = 1u << 16;
+    alignas(64) std::atomic<int> sleepers{0};
+    std::condition_variable cv_work;
     bool session = false, quit = false, pinned = false;
     cpu_set_t caller_mask;
     Seats seats;
@@ -318,7 +323,13 @@ struct Team {
         ops[pending % CAP] = op;
         pending++;
     }
-    inline void publish() { head.store(pending, std::memory_order_release); }
+    inline void publish()
+    {
+        // (seq_cst on both sides: the store of head and the load of sleepers must not pass each other,
+        // nor the helper's increment of sleepers and its last look at head)
+        head.store(pending, std::memory_order_seq_cst);
+        if (sleepers.load(std::memory_order_seq_cst) != 0) { std::lock_guard<std::mutex> lk(mu); cv_work.notify_all(); }
+    }
     void wait(int h0, int h1)
     {
         publish();
@@ -373,10 +384,17 @@ struct Team {
                     idle = 0;
                 } else {
                     _mm_pause();
-                    if (++idle > 8192) {
-                        idle = 0;
+                    ++idle;
+                    if ((idle & 8191) == 0) {
                         std::unique_lock<std::mutex> lk(mu);
                         if (!session) break;
+                        if (idle >= IDLE_SPINS) {
+                            sleepers.fetch_add(1, std::memory_order_seq_cst);
+                            cv_work.wait(lk, [&] { return head.load(std::memory_order_seq_cst) != t || !session; });
+                            sleepers.fetch_sub(1, std::memory_order_seq_cst);
+                            idle = 0;
+                            if (!session) break;
+                        }
                     }
                 }
             }
@@ -416,12 +434,14 @@ struct Team {
         if (pinned) { pthread_setaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask); seats.release(); pinned = false; }
         std::lock_guard<std::mutex> lk(mu);
         session = false;
+        cv_work.notify_all();
     }
     ~Team()
     {
         if (!started) return;
         { std::lock_guard<std::mutex> lk(mu); quit = true; session = false; }
         cv.notify_all();
+        cv_work.notify_all();
         for (int h = 0; h < started; h++) if (th[h].joinable()) th[h].join();
     }
 };

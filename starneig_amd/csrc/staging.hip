@@ -2,8 +2,11 @@
 // column-major arrays, like the reference: common/matrix.c:204-206 views the caller's memory).
 // hipMemcpy2D on pageable memory moves ~25 GB/s on the MI355X box; here a few host threads each
 // run a private two-slot pipeline (memcpy into a pinned slot | async DMA of the other slot), which
-// keeps the PCIe Gen5 link busy.  starneig_node_enable_pinning() registers the caller's arrays
-// instead and the copies go directly.
+// keeps the PCIe Gen5 link busy (~50 GB/s).  starneig_node_enable_pinning() is accepted and changes
+// nothing here: every copy goes through the pinned slots (registering a 3.2 GB array costs more than
+// the extra host memcpy saves).  The lanes belong to the device that was current when they were
+// created and are rebuilt when that changes; one API call at a time (the C interface is not
+// re-entrant, SURVEY 8b "Threading").
 #include "common.h"
 #include <algorithm>
 #include <cstring>
@@ -25,6 +28,7 @@ struct Lane {                       // one thread's pipeline
 struct Stager {
     Lane lane[MAX_THREADS];
     int lanes = 0;
+    int device = -1;                // the device the lanes' streams and events were created on
     void ensure(int n)
     {
         for (; lanes < n; lanes++) {
@@ -99,9 +103,10 @@ void staged_copy(bool to_device, double *dev, int ldd, double *host, int ldh, in
     // small matrices: one lane; large ones: up to MAX_THREADS lanes over contiguous column ranges
     int const want = (int)std::min<size_t>(MAX_THREADS, std::max<size_t>(1, colbytes * cols / (4 * SLOT_BYTES)));
     int const T = std::max(1, std::min(threads, want));
-    g_stager.ensure(T);
     int device = 0;
     SN_HIP_CHECK(hipGetDevice(&device));
+    if (g_stager.device != device) { g_stager.release(); g_stager.device = device; }
+    g_stager.ensure(T);
     std::vector<std::thread> pool;
     int const per = divceil(cols, T);
     for (int t = 1; t < T; t++) {

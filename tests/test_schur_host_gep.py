@@ -186,3 +186,22 @@ def test_gep_aed_window_reorders_to_deflate_more():
     E = Q @ A @ Z.T - A0r
     assert np.linalg.norm(E) <= 1000 * U * np.linalg.norm(A0r)
     assert np.all(np.tril(A, -2) == 0.0) and np.all(np.tril(B, -1) == 0.0) and np.all(A[ns:, :ns] == 0.0)
+
+
+def test_close_real_pair_is_split_and_reported_accurately():
+    """A 2x2 block with two CLOSE real eigenvalues (-4423.496 / -4424.034, relative gap 1e-4), found
+    by the reference's `--init known --generalized` experiment at n = 4000: the quadratic formula on
+    (sum, product) lost the difference to cancellation, the block stayed unsplit and both
+    eigenvalues were reported as their mean (an error of 6e-5 relative = 3e11 u).  The eigenvalues
+    now come from the shifted form LAPACK dlag2 uses (reference common/math.c:148-176)."""
+    L = lib()
+    A0 = np.array([[-3403.648820837277, 0.32292784219672926], [-0.013751781294212357, -1382.9661188795437]])
+    B0 = np.array([[0.7694533042009347, 0.0], [0.0, 0.31260067874299907]])
+    A, B = np.asfortranarray(A0.copy()), np.asfortranarray(B0.copy())
+    Q, Z = np.asfortranarray(np.eye(2)), np.asfortranarray(np.eye(2))
+    ar, ai, be = np.zeros(2), np.zeros(2), np.zeros(2)
+    assert L.sn_internal_gep_small_schur(2, P(A), 2, P(B), 2, P(Q), 2, P(Z), 2, P(ar), P(ai), P(be)) == 0
+    assert A[1, 0] == 0.0 and B[1, 0] == 0.0 and not ai.any()
+    ref = np.sort(sl.eigvals(A0, B0).real)
+    assert np.abs(np.sort(ar / be) - ref).max() <= 100 * U * np.abs(ref).max()
+    check_gschur(A0, B0, A, B, Q, Z, tol=50)
