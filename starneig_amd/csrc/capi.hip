@@ -27,6 +27,13 @@ void reorder_release_workspace();
 void upload_host_matrix(double *dev, int ldd, double const *host, int ldh, int rows, int cols, int threads);
 void download_host_matrix(double *host, int ldh, double const *dev, int ldd, int rows, int cols, int threads);
 void staging_release();
+// several GPUs from one process (node_team.hip)
+void node_team_start(int const *devices, int world);
+void node_team_stop();
+int node_team_world();
+int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, int ldQ, int cores);
+int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real, double *imag,
+    SchurParams const &params, int cores);
 }
 
 namespace {
@@ -35,8 +42,30 @@ struct NodeState {                      // reference: static state, common/node.
     bool initialized = false;
     int cores = 0, gpus = 0, avail_cores = 1;
     bool messages = true, verbose = true, pinning = false;
-    int device = 0;
+    int device = 0, avail_gpus = 1;
 } g_node;
+
+// gpus of starneig_node_init / starneig_node_set_gpus -> ranks of the in-process multi-GPU path
+// (common/node.c:200-216: the reference hands min(requested, present) CUDA devices to StarPU).
+// STARNEIG_AMD_VIRTUAL_GPUS=k (testing on a box with fewer devices): k ranks dealt round-robin over
+// the devices present, collectives through the in-process exchange.
+void configure_gpus(int gpus)
+{
+    int ndev = 1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+    int avail = ndev;
+    if (char const *v = getenv("STARNEIG_AMD_VIRTUAL_GPUS")) avail = std::max(1, std::min(16, atoi(v)));
+    g_node.avail_gpus = avail;
+    int const want = gpus == STARNEIG_USE_ALL ? avail : std::max(1, std::min(gpus, avail));
+    sn::node_team_stop();
+    g_node.gpus = want;
+    if (want > 1) {
+        std::vector<int> devs(want);
+        for (int r = 0; r < want; r++) devs[r] = (g_node.device + r) % ndev;
+        sn::node_team_start(devs.data(), want);
+        if (sn::node_team_world() != want) g_node.gpus = 1;
+    }
+}
 
 void require_device()
 {
@@ -89,9 +118,9 @@ SN_API void starneig_node_init(int cores, int gpus, starneig_flag_t flags)
     g_node.messages = (flags & STARNEIG_NO_MESSAGES) != STARNEIG_NO_MESSAGES;
     require_device();
     // cores: host threads available to the sequential window kernels (the process' affinity
-    // mask, like the hwloc binding mask of common/node.c:497-536); gpus: one process drives ONE
-    // device (multi-GPU runs are one process per GPU over RCCL), so any request other than 0
-    // resolves to 1 and 0 is refused -- there is no CPU path to fall back to.
+    // mask, like the hwloc binding mask of common/node.c:497-536); gpus: the devices of this node that
+    // the calls of this process use (configure_gpus above: one host thread per device); 0 is
+    // refused -- there is no CPU path to fall back to.
     cpu_set_t mask;
     int avail = 1;
     if (sched_getaffinity(0, sizeof mask, &mask) == 0) avail = std::max(1, CPU_COUNT(&mask));
@@ -117,7 +146,7 @@ SN_API void starneig_node_init(int cores, int gpus, starneig_flag_t flags)
             "CPU path.\n");
         abort();
     }
-    g_node.gpus = 1;
+    configure_gpus(gpus);
     g_node.initialized = true;
 }
 
@@ -131,9 +160,11 @@ SN_API void starneig_node_set_cores(int cores)
 SN_API int starneig_node_get_gpus(void) { return g_node.gpus; }
 SN_API void starneig_node_set_gpus(int gpus)
 {
-    if (gpus == 0 && g_node.messages)
-        fprintf(stderr, "[starneig-amd] warning: starneig_node_set_gpus(0) ignored: no CPU path.\n");
-    g_node.gpus = 1;
+    if (gpus == 0) {
+        if (g_node.messages) fprintf(stderr, "[starneig-amd] warning: starneig_node_set_gpus(0) ignored: no CPU path.\n");
+        return;
+    }
+    if (g_node.initialized) configure_gpus(gpus);
 }
 SN_API void starneig_node_enable_pinning(void) { g_node.pinning = true; }
 SN_API void starneig_node_disable_pinning(void) { g_node.pinning = false; }
@@ -141,6 +172,7 @@ SN_API void starneig_node_disable_pinning(void) { g_node.pinning = false; }
 SN_API void starneig_node_finalize(void)
 {
     if (!g_node.initialized) return;
+    sn::node_team_stop();
     SN_HIP_CHECK(hipDeviceSynchronize());
     sn::hessenberg_release_workspace();
     sn::schur_release_workspace();
@@ -200,6 +232,13 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     }
     if (panel_width == STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH)
         panel_width = default_panel_width(n);
+
+    // several GPUs (starneig_node_init(cores, gpus > 1, ...)): the block-column sharded reduction, one
+    // host thread per device (node_team.hip).  Partial ranges and matrices too small to shard stay on
+    // one device.
+    if (g_node.gpus > 1 && begin == 0 && end == n && n >= 256 * g_node.gpus)
+        return sn::node_team_hessenberg(n, panel_width, A, ldA, Q, ldQ, g_node.cores) == 0
+            ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
@@ -313,6 +352,11 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
     int rc = schur_params_from_conf(conf, prm, false);
     if (rc != STARNEIG_SUCCESS) return rc;
     prm.host_threads = g_node.cores;
+
+    if (g_node.gpus > 1 && n >= 256 * g_node.gpus) {
+        if (real == NULL || imag == NULL) real = imag = nullptr;
+        return sn::node_team_schur(n, H, ldH, Q, ldQ, real, imag, prm, g_node.cores);
+    }
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);

@@ -26,26 +26,47 @@
 
 namespace sn {
 
-template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH>
-__global__ __launch_bounds__(256, 2)
-void dgemm_kernel(int m, int n, int k, double alpha,
-    double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double beta, double *__restrict__ C, int ldc, int tiles_m, int separate_sum)
+// tile id -> (bm, bn).  Tile order (speed only): blocks are dealt round-robin over the 8 XCDs, so give
+// every XCD a contiguous range of tile ids (its private L2 then sees neighbouring tiles), and walk the
+// tiles in groups of 8 tile-rows so that the ~64 tiles resident on one XCD cover an 8 x 8 patch: 16
+// operand panels instead of 65.
+__device__ __forceinline__ void tile_of(int pid, int total, int tiles_m, int &bm, int &bn)
 {
-    // Tile order (speed only): blocks are dealt round-robin over the 8 XCDs, so give every
-    // XCD a contiguous range of tile ids (its private L2 then sees neighbouring tiles), and
-    // walk the tiles in groups of 8 tile-rows so that the ~64 tiles resident on one XCD
-    // cover an 8 x 8 patch: 16 operand panels instead of 65.
-    int const nwg = gridDim.x, tiles_n = nwg / tiles_m;
-    int pid = blockIdx.x;
-    int const cpx = nwg / 8;
+    int const tiles_n = total / tiles_m;
+    int const cpx = total / 8;
     if (pid < cpx * 8) pid = (pid % 8) * cpx + pid / 8;
     constexpr int GROUP_M = 8;
     int const in_group = GROUP_M * tiles_n;
     int const group = pid / in_group, first_m = group * GROUP_M;
     int const gsize = min(tiles_m - first_m, GROUP_M);
-    int const bm = first_m + (pid % in_group) % gsize, bn = (pid % in_group) / gsize;
-    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn, false, separate_sum != 0);
+    bm = first_m + (pid % in_group) % gsize; bn = (pid % in_group) / gsize;
+}
+
+// SPLIT: the tiles of the last, partly filled round of workgroups (the chip holds 512 of them) are cut
+// into `pieces` = 2 (halves, BM/2 x BN) or 4 (quarters) so that this round fills the chip too: the first
+// `whole` blocks take whole tiles, the others one piece each of the tiles whole, whole + 1, ...  (the
+// trailing matrix of the Hessenberg reduction shrinks panel by panel: at m = 10000 a launch is 12.2
+// rounds of tiles and paid for 13)
+template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH, bool SPLIT>
+__global__ __launch_bounds__(256, 2)
+void dgemm_kernel(int m, int n, int k, double alpha,
+    double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
+    double beta, double *__restrict__ C, int ldc, int tiles_m, int separate_sum, int total, int whole, int pieces)
+{
+    int bm, bn;
+    if (!SPLIT || (int)blockIdx.x < whole) {
+        tile_of(blockIdx.x, total, tiles_m, bm, bn);
+        gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn, false, separate_sum != 0);
+        return;
+    }
+    if (SPLIT) {
+        int const q = blockIdx.x - whole, piece = q % pieces;
+        tile_of(whole + q / pieces, total, tiles_m, bm, bn);
+        if (pieces == 2)
+            gemm_tile<BM / 2, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + piece, bn, false, separate_sum != 0);
+        else
+            gemm_tile<BM / 2, BN / 2, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + (piece & 1), 2 * bn + (piece >> 1), false, separate_sum != 0);
+    }
 }
 
 // Split-K form for outputs with few tiles and a long inner dimension (the inner-product shaped
@@ -90,7 +111,7 @@ template <int BM, int BN, int KT, bool TA, bool TB>
 static void launch_batched(hipStream_t s, GemmDesc const *ddescs, int count, int max_tiles)
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;      // per host thread = per device
     auto kern = dgemm_batched_kernel<BM, BN, KT, TA, TB>;
     if (!attr_set) {
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
@@ -116,22 +137,30 @@ void dgemm_batched_right_inplace(hipStream_t s, GemmDesc const *ddescs, int coun
 template <int BM, int BN, int KT, bool TA, bool TB>
 static void launch(hipStream_t s, int m, int n, int k, double alpha,
     double const *A, int lda, double const *B, int ldb, double beta,
-    double *C, int ldc)
+    double *C, int ldc, bool split_ok = false)
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;      // per host thread = per device
     // two-level summation (chunks of 256 terms) wherever the second accumulator set fits the
     // register budget of two workgroups per CU: every tile shape but 128 x 128
     constexpr int FLUSH = (BM * BN <= 128 * 64) ? 256 / KT : 0;
-    auto kern = dgemm_kernel<BM, BN, KT, TA, TB, FLUSH>;
+    // the big tile cuts the tiles of its last round of workgroups into pieces (see the kernel)
+    constexpr bool SPLIT = (BM == 128 && BN == 128);
+    auto kern = dgemm_kernel<BM, BN, KT, TA, TB, FLUSH, SPLIT>;
     if (!attr_set) {
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr_set = true;
     }
-    int tiles_m = divceil(m, BM), tiles_n = divceil(n, BN);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), Cfg::LDS_BYTES, s,
-        m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tiles_m, tuning().gemm_separate_sum ? 1 : 0);
+    int const tiles_m = divceil(m, BM), tiles_n = divceil(n, BN), total = tiles_m * tiles_n;
+    int whole = total, pieces = 1;
+    // (never for the in-place window updates below: there ONE workgroup must own all rows / columns of its tile)
+    if (SPLIT && split_ok && !tuning().gemm_nosplit) {
+        int const slots = 512, r = total % slots;
+        if (total > slots && r > 0 && r <= slots / 2) { pieces = (r <= slots / 4) ? 4 : 2; whole = total - r; }
+    }
+    hipLaunchKernelGGL(kern, dim3(whole + (total - whole) * pieces), dim3(256), Cfg::LDS_BYTES, s,
+        m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tiles_m, tuning().gemm_separate_sum ? 1 : 0, total, whole, pieces);
 }
 
 template <int BM, int BN, bool TA, bool TB>
@@ -139,7 +168,7 @@ static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double
     double const *A, int lda, double const *B, int ldb, double *C, int ldc)
 {
     using Cfg = GemmCfg<BM, BN, 16, TA, TB>;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;      // per host thread = per device
     auto kern = dgemm_splitk_kernel<BM, BN, 16, TA, TB, 256 / 16>;
     if (!attr_set) {
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern,
@@ -188,7 +217,7 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
     // few big tiles would also leave most of the 256 CUs idle.
     long tiles128 = (long)divceil(m, 128) * divceil(n, 128);
     if (tiles128 >= 512 && n >= 512)
-        launch<128, 128, 16, TA, TB>(s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+        launch<128, 128, 16, TA, TB>(s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, A != C && B != C);
     else if ((long)divceil(m, 128) * divceil(n, 64) >= 256)
         launch<128, 64, 16, TA, TB>(s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
     else

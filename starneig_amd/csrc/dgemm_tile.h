@@ -180,13 +180,23 @@ void gemm_tile(int m, int n, int k, double alpha,
                 }
             }
     }
+    // Three stages with ONE register set and two LDS buffers: while the MFMAs of k-tile kt run out of
+    // LDS[kt & 1], tile kt + 1 goes from the registers to the other buffer FIRST (its loads were
+    // issued a whole block ago, and that buffer was released by the barrier that ended block kt - 1)
+    // and the loads of tile kt + 2 are issued into the registers just freed.  The end of a block is
+    // then the barrier alone -- not "wait for the loads, write LDS, wait, barrier" with the matrix
+    // pipe idle meanwhile.  (PMC, 20000^2 x 624, two workgroups per CU: the waves were parked at
+    // s_waitcnt / s_barrier for 13 % of their cycles and the two waves of a SIMD reach that tail
+    // together: 74 % MFMA busy.)
     load_tiles(0);
     store_tiles(0, 0);
+    if (nkt > 1) load_tiles(KT);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; kt++) {
         int const buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles((kt + 1) * KT);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * KT);
+        if (kt + 2 < nkt) load_tiles((kt + 2) * KT);
 
         double const *pR = smem + buf * BUF_ELEMS, *pC = pR + Cfg::R_ELEMS;
         #pragma unroll
@@ -219,8 +229,6 @@ void gemm_tile(int m, int n, int k, double alpha,
                     acc[ci][ri] = (kt + 1 == nkt) ? acc2[TWO ? ci : 0][TWO ? ri : 0] : (d4){0.0, 0.0, 0.0, 0.0};
                 }
         }
-
-        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * KT);
         __syncthreads();
     }
 

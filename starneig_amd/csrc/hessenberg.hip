@@ -604,7 +604,9 @@ struct HessWorkspace {
     }
 };
 
-static HessWorkspace g_ws;
+// one workspace per host thread: the single-GPU path runs on the caller's thread, the in-process
+// multi-GPU path (node_team.hip) on one persistent thread per device
+static thread_local HessWorkspace g_ws;
 
 void hessenberg_release_workspace() { g_ws.release(); }
 

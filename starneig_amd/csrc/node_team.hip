@@ -1,0 +1,326 @@
+// Several GPUs of ONE node driven from ONE process: what starneig_node_init(cores, gpus = N, ...)
+// followed by starneig_SEP_SM_Hessenberg / _Schur means in the reference's shared-memory mode
+// (common/node.c:200-216, :435-543: StarPU drives every CUDA device of the node from the calling
+// process).  Here: one persistent host thread per device ("rank"); a call of the C interface hands
+// each thread the same job, the threads run the block-column sharded Hessenberg reduction
+// (hessenberg_sharded_device) or the row-sharded Schur leg (schur_device with q_rows) on their
+// device, and the call returns when all of them are done.  Every per-device object of the library
+// (workspaces, streams, the RCCL communicator, the staging lanes, the helper team of the host window
+// kernel) is thread_local, so a rank is "the library on one thread".
+//
+// Collectives: RCCL (rccl_native.hip, one communicator per thread, ncclCommInitRank from N threads)
+// when the ranks sit on N distinct devices and librccl loads; otherwise -- ranks that share a device
+// (STARNEIG_AMD_VIRTUAL_GPUS, the mode the one-GPU test box uses) or no RCCL -- an in-process
+// exchange: the ranks meet at a barrier, read each other's device buffers (same device, or peers)
+// and sum them in rank order, so every rank gets the same bits.
+#include "common.h"
+#include "tuning.h"
+#include <atomic>
+#include <cmath>
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <immintrin.h>
+
+namespace sn {
+
+void hessenberg_release_workspace();
+void upload_host_matrix(double *dev, int ldd, double const *host, int ldh, int rows, int cols, int threads);
+void download_host_matrix(double *host, int ldh, double const *dev, int ldd, int rows, int cols, int threads);
+void staging_release();
+
+namespace {
+
+constexpr int MAX_RANKS = 16;
+
+struct PtrTable { double const *p[MAX_RANKS]; };
+
+// out[i] = sum over ranks (in rank order) of src[r][i]
+__global__ void team_sum_kernel(double *__restrict__ out, PtrTable src, int world, long count)
+{
+    long const i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = src.p[0][i];
+    for (int r = 1; r < world; r++) s += src.p[r][i];
+    out[i] = s;
+}
+
+// all threads of the team meet here; spins briefly, then yields (a collective is tens of microseconds)
+struct SpinBarrier {
+    std::atomic<int> count{0};
+    std::atomic<unsigned> gen{0};
+    int n = 1;
+    void wait()
+    {
+        unsigned const g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+            return;
+        }
+        for (unsigned spins = 0; gen.load(std::memory_order_acquire) == g; spins++) {
+            if (spins < 4096) _mm_pause(); else std::this_thread::yield();
+        }
+    }
+};
+
+struct Team {
+    int world = 0;
+    std::vector<int> device;
+    bool use_rccl = false;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    unsigned job_gen = 0;
+    int done = 0;
+    bool quit = false;
+    SpinBarrier bar;
+    // in-process collectives: the buffer every rank brought to the current call, a scratch per rank
+    double *xptr[MAX_RANKS] = {};
+    double *tmp[MAX_RANKS] = {};
+    long tmp_cap[MAX_RANKS] = {};
+    hipStream_t stream[MAX_RANKS] = {};
+
+    void worker(int rank)
+    {
+        SN_HIP_CHECK(hipSetDevice(device[rank]));
+        SN_HIP_CHECK(hipStreamCreateWithFlags(&stream[rank], hipStreamNonBlocking));
+        unsigned seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return quit || job_gen != seen; });
+                if (quit) break;
+                seen = job_gen; f = job;
+            }
+            f(rank);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (++done == world) cv_done.notify_all();
+            }
+        }
+        // this thread's share of the library's cached state
+        SN_HIP_CHECK(hipDeviceSynchronize());
+        hessenberg_release_workspace();
+        schur_release_workspace();
+        staging_release();
+        rccl_finalize();
+        if (tmp[rank]) { SN_HIP_CHECK(hipFree(tmp[rank])); tmp[rank] = nullptr; tmp_cap[rank] = 0; }
+        SN_HIP_CHECK(hipStreamDestroy(stream[rank]));
+    }
+    void run(std::function<void(int)> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(f); done = 0; job_gen++;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return done == world; });
+    }
+    void start(std::vector<int> const &devs, bool rccl_wanted)
+    {
+        world = (int)devs.size(); device = devs; bar.n = world; quit = false;
+        job_gen = 0; job = nullptr; done = 0;       // (no worker is alive here: the new ones start level with the counter)
+        for (int r = 0; r < world; r++) th.emplace_back([this, r] { worker(r); });
+        // distinct devices: RCCL if it loads and every rank gets its communicator
+        bool distinct = true;
+        for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (devs[a] == devs[b]) distinct = false;
+        use_rccl = false;
+        if (rccl_wanted && distinct && world > 1) {
+            unsigned char id[128];
+            if (rccl_unique_id(id) == 0) {
+                std::atomic<int> ok{0};
+                run([&](int rank) { if (rccl_init(rank, world, id) == 0) ok++; });
+                use_rccl = ok.load() == world;
+                if (!use_rccl) run([&](int) { rccl_finalize(); });
+            }
+        }
+        if (!use_rccl && distinct && world > 1) {
+            // the in-process exchange reads peer memory from kernels
+            run([&](int rank) {
+                for (int r = 0; r < world; r++)
+                    if (r != rank) { hipError_t e = hipDeviceEnablePeerAccess(device[r], 0); (void)e; (void)hipGetLastError(); }
+            });
+        }
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_job.notify_all();
+        for (auto &t : th) t.join();
+        th.clear(); world = 0;
+    }
+
+    // ---- collectives of one rank (called from its thread, same order on every rank) ----------
+    void allreduce(int rank, double *buf, long count, hipStream_t s)
+    {
+        if (use_rccl) { if (rccl_allreduce_sum(buf, count, s) != 0) abort(); return; }
+        if (tmp_cap[rank] < count) {
+            if (tmp[rank]) SN_HIP_CHECK(hipFree(tmp[rank]));
+            tmp_cap[rank] = count + count / 4 + 4096;
+            SN_HIP_CHECK(hipMalloc((void **)&tmp[rank], (size_t)tmp_cap[rank] * 8));
+        }
+        SN_HIP_CHECK(hipStreamSynchronize(s));          // my contribution is complete
+        xptr[rank] = buf;
+        bar.wait();
+        PtrTable t;
+        for (int r = 0; r < world; r++) t.p[r] = xptr[r];
+        hipLaunchKernelGGL(team_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, tmp[rank], t, world, count);
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        bar.wait();                                     // everybody has read everybody's buffer
+        SN_HIP_CHECK(hipMemcpyAsync(buf, tmp[rank], (size_t)count * 8, hipMemcpyDeviceToDevice, s));
+    }
+    void broadcast(int rank, double *buf, long count, int root, hipStream_t s)
+    {
+        if (use_rccl) { if (rccl_broadcast(buf, count, root, s) != 0) abort(); return; }
+        if (rank == root) SN_HIP_CHECK(hipStreamSynchronize(s));
+        xptr[rank] = buf;
+        bar.wait();
+        if (rank != root) {
+            SN_HIP_CHECK(hipMemcpyAsync(buf, xptr[root], (size_t)count * 8, hipMemcpyDefault, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        bar.wait();                                     // the root may overwrite its buffer again
+    }
+};
+
+Team g_team;
+
+struct RankComm { Team *team; int rank; double *buf[5]; hipStream_t s; };
+void team_allreduce_cb(void *ctx, int buffer, long offset, long count)
+{
+    RankComm *c = (RankComm *)ctx;
+    c->team->allreduce(c->rank, c->buf[buffer] + offset, count, c->s);
+}
+void team_broadcast_cb(void *ctx, int buffer, long offset, long count, int root)
+{
+    RankComm *c = (RankComm *)ctx;
+    c->team->broadcast(c->rank, c->buf[buffer] + offset, count, root, c->s);
+}
+
+} // namespace
+
+int node_team_world() { return g_team.world; }
+bool node_team_uses_rccl() { return g_team.use_rccl; }
+
+// devices[r] = the device of rank r (the same device may appear more than once: virtual ranks)
+void node_team_start(int const *devices, int world)
+{
+    if (g_team.world) g_team.stop();
+    if (world < 2) return;
+    if (world > MAX_RANKS) world = MAX_RANKS;
+    g_team.start(std::vector<int>(devices, devices + world), getenv("STARNEIG_AMD_NO_RCCL") == nullptr);
+}
+void node_team_stop() { if (g_team.world) g_team.stop(); }
+
+// The reduction of the whole matrix on all ranks: A, Q are the caller's host arrays.  Every rank
+// uploads the matrix, the sharded reduction leaves the assembled H and Q on every rank, and every
+// rank brings a share of the columns back (N PCIe links instead of one).
+int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, int ldQ, int cores)
+{
+    Team &T = g_team;
+    int const world = T.world;
+    int const ld = (int)roundup(n, 16), ldp = hessenberg_panel_ld(n, panel_width);
+    int const threads = std::max(1, cores / world);
+    std::atomic<int> failures{0};
+    T.run([&](int rank) {
+        hipStream_t s = T.stream[rank];
+        size_t const bytes = (size_t)ld * n * 8;
+        double *dA = nullptr, *dQ = nullptr, *dY = nullptr, *dP = nullptr, *dW = nullptr;
+        SN_HIP_CHECK(hipMalloc((void **)&dA, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+        SN_HIP_CHECK(hipMalloc((void **)&dY, (size_t)ldp * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dP, (size_t)ldp * panel_width * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dW, (size_t)n * panel_width * 8));
+        SN_HIP_CHECK(hipMemsetAsync(dA, 0, bytes, s)); SN_HIP_CHECK(hipMemsetAsync(dQ, 0, bytes, s));
+        SN_HIP_CHECK(hipMemsetAsync(dY, 0, (size_t)ldp * 8, s));
+        SN_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)ldp * panel_width * 8, s));
+        SN_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)n * panel_width * 8, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        upload_host_matrix(dA, ld, A, ldA, n, n, threads);
+        upload_host_matrix(dQ, ld, Q, ldQ, n, n, threads);
+        T.bar.wait();                                   // nobody writes into A / Q before everybody has read them
+        RankComm rc{&T, rank, {dY, dP, dW, dA, dQ}, s};
+        HessComm comm{rank, world, team_allreduce_cb, team_broadcast_cb, &rc};
+        int const r = hessenberg_sharded_device(s, n, panel_width, dA, ld, dQ, ld, dY, dP, dW,
+            (long)n * panel_width, comm, nullptr);
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        if (r != 0) failures++;
+        int const per = divceil(n, world), c0 = std::min(n, rank * per), c1 = std::min(n, c0 + per);
+        if (c1 > c0) {
+            download_host_matrix(A + (size_t)c0 * ldA, ldA, dA + (size_t)c0 * ld, ld, n, c1 - c0, threads);
+            download_host_matrix(Q + (size_t)c0 * ldQ, ldQ, dQ + (size_t)c0 * ld, ld, n, c1 - c0, threads);
+        }
+        for (double *p : {dA, dQ, dY, dP, dW}) SN_HIP_CHECK(hipFree(p));
+    });
+    return failures.load() == 0 ? 0 : 1;
+}
+
+// Schur leg: every rank reduces a replica of H and accumulates its row block of Q;
+// rank 0 brings H and the eigenvalues back, every rank its rows of Q.  The replicas must agree bit for
+// bit: a checksum of the eigenvalues and of diag(S) is compared before anything is written back.
+int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real, double *imag,
+    SchurParams const &params, int cores)
+{
+    Team &T = g_team;
+    int const world = T.world;
+    int const ld = (int)roundup(n, 16);
+    int const threads = std::max(1, cores / world);
+    int const qchunk = (int)roundup(divceil(n, world), 128);
+    std::vector<int> rcs(world, 0);
+    std::vector<std::vector<double>> wr(world), wi(world), chk(world);
+    std::vector<double *> dHs(world, nullptr), dQs(world, nullptr);
+    T.run([&](int rank) {
+        int const r0 = std::min(n, rank * qchunk), r1 = std::min(n, (rank + 1) * qchunk), rows = r1 - r0;
+        if (rows <= 0) return;
+        hipStream_t s = T.stream[rank];
+        size_t const bytes = (size_t)ld * n * 8;
+        double *dH = nullptr, *dQ = nullptr;
+        SN_HIP_CHECK(hipMalloc((void **)&dH, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+        SN_HIP_CHECK(hipMemsetAsync(dH, 0, bytes, s)); SN_HIP_CHECK(hipMemsetAsync(dQ, 0, bytes, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        upload_host_matrix(dH, ld, H, ldH, n, n, threads);
+        upload_host_matrix(dQ + r0, ld, Q + r0, ldQ, rows, n, threads);
+        SchurParams prm = params;
+        prm.host_threads = threads;
+        wr[rank].assign(n, 0.0); wi[rank].assign(n, 0.0);
+        rcs[rank] = schur_device(s, n, dH, ld, dQ + r0, ld, wr[rank].data(), wi[rank].data(), prm, nullptr, rows);
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<double> dg(n);
+        SN_HIP_CHECK(hipMemcpy2D(dg.data(), 8, dH, (size_t)(ld + 1) * 8, 8, n, hipMemcpyDeviceToHost));
+        double a = 0, b = 0, c = 0, d = 0;
+        for (int i = 0; i < n; i++) { a += dg[i]; b += dg[i] * dg[i]; c += wr[rank][i]; d += std::fabs(wi[rank][i]); }
+        chk[rank] = {a, b, c, d, (double)rcs[rank]};
+        dHs[rank] = dH; dQs[rank] = dQ;
+    });
+    int first = -1, rc = 0;
+    bool same = true;
+    for (int r = 0; r < world; r++) {
+        if (chk[r].empty()) continue;
+        if (first < 0) { first = r; rc = rcs[r]; continue; }
+        if (std::memcmp(chk[r].data(), chk[first].data(), chk[r].size() * 8) != 0) same = false;
+    }
+    if (!same) {
+        fprintf(stderr, "[starneig-amd] the replicas of H diverged in the sharded Schur leg; nothing was written back\n");
+        rc = 1;     // STARNEIG_GENERIC_ERROR
+    }
+    T.run([&](int rank) {
+        if (!dHs[rank]) return;
+        int const r0 = std::min(n, rank * qchunk), r1 = std::min(n, (rank + 1) * qchunk), rows = r1 - r0;
+        if (same) {
+            download_host_matrix(Q + r0, ldQ, dQs[rank] + r0, ld, rows, n, threads);
+            if (rank == first) download_host_matrix(H, ldH, dHs[rank], ld, n, n, threads);
+        }
+        SN_HIP_CHECK(hipFree(dHs[rank])); SN_HIP_CHECK(hipFree(dQs[rank]));
+    });
+    if (same && first >= 0 && real && imag) {
+        std::memcpy(real, wr[first].data(), (size_t)n * 8);
+        std::memcpy(imag, wi[first].data(), (size_t)n * 8);
+    }
+    return rc;
+}
+
+} // namespace sn

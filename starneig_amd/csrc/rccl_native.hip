@@ -7,6 +7,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <rccl/rccl.h>
 
 namespace sn {
@@ -22,8 +23,6 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclComm_t comm = nullptr;
-    int rank = -1, world = 0;
     bool load()
     {
         if (handle) return true;
@@ -55,12 +54,19 @@ struct RcclApi {
         return true;
     }
 };
-RcclApi g_rccl;
+RcclApi g_api;
+std::once_flag g_api_once;
+// the communicator of the calling thread: one per process in the one-process-per-GPU mode, one per
+// device thread in the in-process multi-GPU mode (node_team.hip)
+struct RcclComm { ncclComm_t comm = nullptr; int rank = -1, world = 0; };
+thread_local RcclComm g_comm;
+struct { RcclApi *operator->() { std::call_once(g_api_once, [] { g_api.load(); }); return &g_api; } } g_rccl;
+bool api_ready() { return g_rccl->handle != nullptr; }
 
 bool check(ncclResult_t r, const char *what)
 {
     if (r == ncclSuccess) return true;
-    fprintf(stderr, "[starneig-amd] RCCL %s failed: %s\n", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    fprintf(stderr, "[starneig-amd] RCCL %s failed: %s\n", what, g_rccl->GetErrorString ? g_rccl->GetErrorString(r) : "?");
     return false;
 }
 
@@ -68,42 +74,42 @@ bool check(ncclResult_t r, const char *what)
 
 int rccl_unique_id(void *id128)
 {
-    if (!g_rccl.load()) return 1;
+    if (!api_ready()) return 1;
     ncclUniqueId id;
-    if (!check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId")) return 2;
+    if (!check(g_rccl->GetUniqueId(&id), "ncclGetUniqueId")) return 2;
     std::memcpy(id128, &id, sizeof id);
     return 0;
 }
 
 int rccl_init(int rank, int world, void const *id128)
 {
-    if (!g_rccl.load()) return 1;
-    if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
+    if (!api_ready()) return 1;
+    if (g_comm.comm) { g_rccl->CommDestroy(g_comm.comm); g_comm.comm = nullptr; }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
-    if (!check(g_rccl.CommInitRank(&g_rccl.comm, world, id, rank), "ncclCommInitRank")) { g_rccl.comm = nullptr; return 2; }
-    g_rccl.rank = rank; g_rccl.world = world;
+    if (!check(g_rccl->CommInitRank(&g_comm.comm, world, id, rank), "ncclCommInitRank")) { g_comm.comm = nullptr; return 2; }
+    g_comm.rank = rank; g_comm.world = world;
     return 0;
 }
 
 void rccl_finalize()
 {
-    if (g_rccl.comm) { g_rccl.CommDestroy(g_rccl.comm); g_rccl.comm = nullptr; }
-    g_rccl.rank = -1; g_rccl.world = 0;
+    if (g_comm.comm) { g_rccl->CommDestroy(g_comm.comm); g_comm.comm = nullptr; }
+    g_comm.rank = -1; g_comm.world = 0;
 }
 
-bool rccl_ready(int rank, int world) { return g_rccl.comm && g_rccl.rank == rank && g_rccl.world == world; }
+bool rccl_ready(int rank, int world) { return g_comm.comm && g_comm.rank == rank && g_comm.world == world; }
 
 int rccl_allreduce_sum(double *buf, long count, hipStream_t s)
 {
-    if (!g_rccl.comm) return 1;
-    return check(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_rccl.comm, s), "ncclAllReduce") ? 0 : 2;
+    if (!g_comm.comm) return 1;
+    return check(g_rccl->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_comm.comm, s), "ncclAllReduce") ? 0 : 2;
 }
 
 int rccl_broadcast(double *buf, long count, int root, hipStream_t s)
 {
-    if (!g_rccl.comm) return 1;
-    return check(g_rccl.Broadcast(buf, buf, (size_t)count, ncclDouble, root, g_rccl.comm, s), "ncclBroadcast") ? 0 : 2;
+    if (!g_comm.comm) return 1;
+    return check(g_rccl->Broadcast(buf, buf, (size_t)count, ncclDouble, root, g_comm.comm, s), "ncclBroadcast") ? 0 : 2;
 }
 
 } // namespace sn

@@ -25,7 +25,6 @@
 #include "dgemm_tile.h"
 #include "schur_common.h"
 #include "tuning.h"
-#include "schur_agg.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -396,23 +395,12 @@ struct SchurWorkspace {
     long issued_total = 0, z_total = 0;
     int guard_row = 0;          // R1: rows >= guard_row are always updated timely
     hipEvent_t lazy_mark = nullptr;
-    // aggregated lazy updates (schur_agg.h): a pool of G matrices reused by every flush (the lazy
-    // streams order the reuse) and a ring of tile descriptors in pinned host memory that the
-    // kernels read directly (no staging copy, nothing for the host to wait on)
-    int agg_tcap = 0;           // tiles of one chunk
-    long agg_chunks = 0;
-    double *dAggG = nullptr, *dAggGq = nullptr;     // one pool per lazy stream (H, Q)
-    AggTile *hAggTiles = nullptr;
-    static constexpr int AGG_DESC_RING = 1 << 15;
-    long agg_desc_head = 0;     // descriptors handed out so far
-    std::vector<long> agg_desc_flush = std::vector<long>(AGG_DESC_RING / 256, -1);   // flush that last used a 256-slot block
 
     void release() {
         void **dptrs[] = {(void **)&dU, (void **)&dShiftR, (void **)&dShiftI,
-            (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc, (void **)&dZq, (void **)&dTmpQ, (void **)&dTmpH,
-            (void **)&dAggG, (void **)&dAggGq};
+            (void **)&dSub, (void **)&dWin, (void **)&dZ, (void **)&dTmp, (void **)&dAcc, (void **)&dZq, (void **)&dTmpQ, (void **)&dTmpH};
         for (auto p : dptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
-        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hShift, (void **)&hAggTiles};
+        void **hptrs[] = {(void **)&hWin, (void **)&hZ, (void **)&hSub, (void **)&hShift};
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
         n = nwmax = max_chains = 0;
     }
@@ -433,11 +421,6 @@ struct SchurWorkspace {
         SN_HIP_CHECK(hipMalloc((void **)&dZ, (size_t)nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmp, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dAcc, 4 * 8));
-        agg_tcap = std::max(32, std::min(1024, n / 16));
-        SN_HIP_CHECK(hipMalloc((void **)&dAggG, (size_t)agg_tcap * AGG_W * AGG_W * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dAggGq, (size_t)agg_tcap * AGG_W * AGG_W * 8));
-        SN_HIP_CHECK(hipHostMalloc((void **)&hAggTiles, (size_t)AGG_DESC_RING * sizeof(AggTile), hipHostMallocDefault));
-        agg_desc_head = 0; std::fill(agg_desc_flush.begin(), agg_desc_flush.end(), -1L);
         SN_HIP_CHECK(hipHostMalloc((void **)&hWin, (size_t)(nwmax + 24) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hZ, (size_t)(nwmax + 24) * nwmax * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
@@ -495,17 +478,12 @@ struct SchurWorkspace {
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<1>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)agg_leftover_kernel,
-                hipFuncAttributeMaxDynamicSharedMemorySize, AGG_LEFTOVER_LDS));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)agg_build_kernel,
-                hipFuncAttributeMaxDynamicSharedMemorySize, AGG_BUILD_LDS));
-            agg_set_attributes();
             attr_set = true;
         }
     }
 };
 // level 0: the caller's matrix; level 1: the private AED window of a blocked AED (large_aed)
-static SchurWorkspace g_sws[2];
+static thread_local SchurWorkspace g_sws[2];      // per host thread (= per device of the in-process multi-GPU path)
 
 // private matrices of the blocked AED (row S5): the window T, its Schur vectors Z, the padded
 // matrix of the re-Hessenberg step and its transformation
@@ -528,7 +506,7 @@ struct LargeAedBuffers {
         SN_HIP_CHECK(hipMalloc((void **)&dZl, (size_t)128 * 128 * 8));
     }
 };
-static LargeAedBuffers g_large;
+static thread_local LargeAedBuffers g_large;
 void schur_release_workspace() { g_sws[0].release(); g_sws[1].release(); g_large.release(); }
 
 // LAPACK iparmq-style minimum, then the reference's rules (schur/process_args.c:116-162)
@@ -864,111 +842,6 @@ struct Driver {
     double prof_la_t0 = 0; hipEvent_t prof_la_ev = nullptr;
     struct LazyItem { SweepStep step; int ev; int row_split; };
     std::vector<LazyItem> lazy;
-    // descriptors for `count` tiles from the pinned ring (contiguous); the blocks they cover were
-    // last used many flushes ago -- if the lazy streams are still behind that flush, wait for them
-    AggTile *agg_descs(int count)
-    {
-        constexpr int RING = SchurWorkspace::AGG_DESC_RING;
-        long head = ws.agg_desc_head;
-        // a 256-slot block belongs to ONE flush (so that a block met with another flush's mark is a
-        // genuine re-use after the ring has wrapped, not the neighbour of the previous flush)
-        if (head % 256 != 0 && ws.agg_desc_flush[(head / 256) % (RING / 256)] != ws.flush_total) head += 256 - head % 256;
-        if (head % RING + count > RING) head += RING - head % RING;        // no wrap inside a chunk
-        for (long b = head / 256; b <= (head + count - 1) / 256; b++) {
-            long &f = ws.agg_desc_flush[b % (RING / 256)];
-            if (f >= 0 && f != ws.flush_total) {
-                if (ws.flush_total - f < SchurWorkspace::FLUSH_RING) {
-                    SN_HIP_CHECK(hipEventSynchronize(ws.q_done[(int)(f % SchurWorkspace::FLUSH_RING)]));
-                    SN_HIP_CHECK(hipEventSynchronize(ws.h_done[(int)(f % SchurWorkspace::FLUSH_RING)]));
-                } else { SN_HIP_CHECK(hipStreamSynchronize(ws.qs)); SN_HIP_CHECK(hipStreamSynchronize(ws.hs)); }
-            }
-            f = ws.flush_total;
-        }
-        ws.agg_desc_head = head + count;
-        return ws.hAggTiles + head % RING;
-    }
-
-    // Aggregated form of the lazy updates of the batch (schur_agg.h): the window factors are cut into
-    // tiles of up to 4 x 4 (steps x chains), every tile's ordered product G is formed by a small
-    // kernel and applied as ONE k ~ 400 in-place product, wavefront by wavefront:
-    //   hs: G;  the rows [tile.rs, factor.rs) of H factor by factor;  H(0:tile.rs, R) <- . G;
-    //       H(R, col_split:n) <- G^T .
-    //   qs: Q(:, R) <- . G
-    AggPlan agg_plan_;
-    std::vector<SweepStep> agg_steps_;
-    double agg_extra_flops = 0.0;
-    double prof_agg_plan = 0, prof_agg_desc = 0, prof_agg_launch = 0; long prof_agg_tiles = 0, prof_agg_flushes = 0, prof_agg_launches = 0;
-    void flush_lazy_aggregated(std::vector<LazyItem> const &lazy, int col_split, bool do_h, bool do_q)
-    {
-        double const tp0 = wall();
-        agg_steps_.clear();
-        for (LazyItem const &it : lazy) agg_steps_.push_back(it.step);
-        agg_plan(agg_steps_,
-            [&](size_t i) { return (double const *)(ws.dU + (size_t)lazy[i].ev * ws.max_chains * WS_MAX * WS_MAX); },
-            [&](size_t i) { return lazy[i].row_split; }, agg_plan_);
-        int const nwaves = (int)agg_plan_.wave_begin.size() - 1;
-        int const lazy_cols = n - col_split;
-        prof_agg_plan += wall() - tp0; prof_agg_tiles += (long)agg_plan_.tiles.size(); prof_agg_flushes++;
-        int w = 0;
-        while (w < nwaves) {
-            double const td0 = wall();
-            // a chunk: whole wavefronts, at most agg_tcap tiles (they share the pool of G matrices;
-            // the streams order the reuse)
-            int w1 = w, cnt = 0;
-            while (w1 < nwaves && cnt + (agg_plan_.wave_begin[w1 + 1] - agg_plan_.wave_begin[w1]) <= ws.agg_tcap) {
-                cnt += agg_plan_.wave_begin[w1 + 1] - agg_plan_.wave_begin[w1]; w1++;
-            }
-            if (w1 == w) { fprintf(stderr, "[starneig-amd] aggregated update: wavefront larger than the pool\n"); abort(); }
-            int const t0 = agg_plan_.wave_begin[w];
-            // (the ring is pinned, device-visible host memory: written once with one streaming copy and
-            // never read by the host -- CPU reads of it cost ~15 us each).  The two lazy streams are
-            // independent: each forms its own copy of the G matrices (a build costs 1 % of an apply),
-            // so the H stream -- which the critical stream waits for -- never waits for the Q stream.
-            AggTile const *tiles = agg_plan_.tiles.data() + t0;
-            AggTile *descs = agg_descs(cnt);
-            for (int k = 0; k < cnt; k++) agg_plan_.tiles[t0 + k].G = ws.dAggG + (size_t)k * AGG_W * AGG_W;
-            std::memcpy(descs, tiles, (size_t)cnt * sizeof(AggTile));
-            prof_agg_desc += wall() - td0;
-            double const tl0 = wall();
-            if (do_h) hipLaunchKernelGGL(agg_build_kernel, dim3(AGG_W / AGG_SLAB, cnt), dim3(256), AGG_BUILD_LDS, ws.hs, descs);
-            for (int v = w; v < w1 && do_h; v++) {
-                int const b = agg_plan_.wave_begin[v] - t0, e = agg_plan_.wave_begin[v + 1] - t0;
-                int max_rs = 0, max_left = 0, maxW = 0;
-                for (int k = b; k < e; k++) {
-                    max_rs = std::max(max_rs, tiles[k].rs); maxW = std::max(maxW, tiles[k].W);
-                    for (int i = 0; i < tiles[k].nfac; i++) max_left = std::max(max_left, tiles[k].f[i].rs - tiles[k].rs);
-                }
-                if (max_left > 0)
-                    hipLaunchKernelGGL(agg_leftover_kernel, dim3(divceil(max_left, 128), e - b), dim3(256), AGG_LEFTOVER_LDS,
-                        ws.hs, descs + b, H, ldH);
-                if (max_rs > 0) agg_launch_right(ws.hs, maxW, divceil(max_rs, AGG_BM), e - b, descs + b, H, ldH, 0, 1);
-                if (lazy_cols > 0) agg_launch_left(ws.hs, maxW, divceil(lazy_cols, AGG_BM), e - b, descs + b, H, ldH, col_split, n);
-            }
-            if (do_q) {
-                AggTile *descsq = agg_descs(cnt);
-                for (int k = 0; k < cnt; k++) agg_plan_.tiles[t0 + k].G = ws.dAggGq + (size_t)k * AGG_W * AGG_W;
-                std::memcpy(descsq, tiles, (size_t)cnt * sizeof(AggTile));
-                hipLaunchKernelGGL(agg_build_kernel, dim3(AGG_W / AGG_SLAB, cnt), dim3(256), AGG_BUILD_LDS, ws.qs, descsq);
-                for (int v = w; v < w1; v++) {
-                    int const b = agg_plan_.wave_begin[v] - t0, e = agg_plan_.wave_begin[v + 1] - t0;
-                    int maxW = 0;
-                    for (int k = b; k < e; k++) maxW = std::max(maxW, tiles[k].W);
-                    agg_launch_right(ws.qs, maxW, divceil(nq, AGG_BM), e - b, descsq + b, Q, ldQ, nq, 0);
-                }
-            }
-            ws.agg_chunks++;
-            prof_agg_launch += wall() - tl0; prof_agg_launches += (w1 - w) * 4 + 1;
-            w = w1;
-        }
-        // executed flops: 2 W^2 per row / column and tile instead of 2 n_f^2 per factor (the rows
-        // between tile.rs and factor.rs are counted with the factors either way)
-        for (AggTile const &t : agg_plan_.tiles) {
-            double std_flops = 0.0;
-            for (int i = 0; i < t.nfac; i++) std_flops += 2.0 * t.f[i].n * t.f[i].n;
-            agg_extra_flops += (2.0 * t.W * t.W - std_flops) * ((do_q ? nq : 0) + (do_h ? (double)t.rs + lazy_cols : 0.0));
-        }
-    }
-
     void launch_q(std::vector<LazyItem> const &items)
     {
         for (LazyItem const &it : items) {
@@ -987,22 +860,17 @@ struct Driver {
         int const fslot = (int)(ws.flush_total % SchurWorkspace::FLUSH_RING);
         SN_HIP_CHECK(hipStreamWaitEvent(ws.hs, ws.far_done[last_ev], 0));
         if (Q) SN_HIP_CHECK(hipStreamWaitEvent(ws.qs, ws.near_done[last_ev], 0));
-        bool const aggregate = agg_on && lazy.size() >= 8 && agg_geometry_ok(lazy.front().step);
-        bool const agg_hpart = aggregate && agg_h;
         for (LazyItem const &it : lazy) {
-            if (!agg_hpart) {
-                int const ntasks = it.step.ntasks;
-                double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
-                int const lazy_cols = n - col_split, lazy_rows = it.row_split;
-                if (lazy_cols > 0 || lazy_rows > 0)
-                    hipLaunchKernelGGL(schur_update_pair_kernel,
-                        dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
-                        UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
-            }
+            int const ntasks = it.step.ntasks;
+            double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
+            int const lazy_cols = n - col_split, lazy_rows = it.row_split;
+            if (lazy_cols > 0 || lazy_rows > 0)
+                hipLaunchKernelGGL(schur_update_pair_kernel,
+                    dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
+                    UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
             ws.slot_flush[it.ev] = ws.flush_total;
         }
-        if (aggregate) flush_lazy_aggregated(lazy, col_split, agg_hpart, Q != nullptr);
-        else if (Q) launch_q(lazy);
+        if (Q) launch_q(lazy);
         SN_HIP_CHECK(hipEventRecord(ws.h_done[fslot], ws.hs));
         if (Q) SN_HIP_CHECK(hipEventRecord(ws.q_done[fslot], ws.qs));
         ws.flush_total++;
@@ -1026,8 +894,6 @@ struct Driver {
     int spw_cap = -1;           // conf->shifts_per_window (process_args.c:418-437)
     long chain_passes = 0;      // chains over all sweeps: the rounding error grows like its square root
     int lazy_batch = tuning().schur_lazy_batch;
-    bool agg_on = tuning().schur_aggregate > 0;
-    bool agg_h = tuning().schur_aggregate != 2;         // 2: aggregate the Q updates only
 
     void sweep_begin(int ilo, int ihi, int nshifts, double const *sr, double const *si)
     {
@@ -1154,8 +1020,7 @@ struct Driver {
             // Phase A of a look-ahead sweep is off the host's critical path and latency-bound on
             // the GPU: its lazy updates are issued in small batches and fill the idle CUs, so that
             // they are through when the AED chain ends.  Otherwise they wait for the sweep's end.
-            // (aggregated flushes cut the batch into tiles that span ~10 steps: longer batches, fewer clipped tiles)
-            int const batch = (limit < ihi) ? (agg_on ? std::max(lazy_batch, 96) : lazy_batch) : ws.ring / 2;
+            int const batch = (limit < ihi) ? lazy_batch : ws.ring / 2;
             if ((int)lazy.size() >= batch) flush_lazy(col_split);
             sw.issued++;
             ws.issued_total++;
@@ -1173,8 +1038,8 @@ struct Driver {
         flush_lazy(sw.col_split);
         sw.active = false;
         st.sweeps++;
-        st.gemm_flops += sweep_flops + agg_extra_flops; st.chase_launches += sweep_launches;
-        sweep_flops = 0.0; sweep_launches = 0; agg_extra_flops = 0.0;
+        st.gemm_flops += sweep_flops; st.chase_launches += sweep_launches;
+        sweep_flops = 0.0; sweep_launches = 0;
     }
 
     void sweep(int ilo, int ihi, int nshifts, double const *sr, double const *si)
@@ -1191,8 +1056,8 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 {
     // the whole reduction runs on the library's own stream pair (never on the legacy NULL
     // stream), fenced against the caller's stream at entry and exit
-    static hipStream_t own_[2] = {nullptr, nullptr};
-    static hipEvent_t fence_[2] = {nullptr, nullptr};
+    static thread_local hipStream_t own_[2] = {nullptr, nullptr};
+    static thread_local hipEvent_t fence_[2] = {nullptr, nullptr};
     hipStream_t &own = own_[level];
     hipEvent_t &fence = fence_[level];
     if (!own) {
@@ -1512,9 +1377,6 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     SN_HIP_CHECK(hipEventSynchronize(e1));
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
-    if (tuning().schur_profile && d.prof_agg_flushes > 0)
-        fprintf(stderr, "[schur] aggregated flushes %ld, tiles %ld, ~launches %ld: plan %.3f s, descriptors %.3f s, launches %.3f s\n",
-            d.prof_agg_flushes, d.prof_agg_tiles, d.prof_agg_launches, d.prof_agg_plan, d.prof_agg_desc, d.prof_agg_launch);
     if (tuning().schur_profile && d.prof_laed_calls > 0)
         fprintf(stderr, "[schur] blocked AED: %d calls, %d deflation windows: Schur form of the window %.3f s, deflation / reordering %.3f s, "
             "re-Hessenberg %.3f s, write-back and updates (issue) %.3f s\n", d.prof_laed_calls, d.prof_laed_windows,
@@ -1534,138 +1396,6 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 } // namespace sn
 
 #ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
-// ---- test hook (tests/test_gpu_schur_agg.py): the aggregated lazy update of schur_agg.h on its own.
-// The window steps t_first..t_last of a sweep with the given geometry; U: the factors in issue order
-// (step by step, chain by chain), each a 96 x 96 column-major block; mode 0: X(0:m, :) <- X . (product
-// of the factors, columns of the windows); mode 1: X(:, c_lo:c_hi) <- (product)^T . X (rows of the windows).
-// X is a host array (ldx x ncols), updated in place.  Returns the number of tiles, < 0 on error.
-extern "C" __attribute__((visibility("default")))
-int sn_internal_agg_apply(int mode, int ilo, int ihi, int ws_, int nbc, int chains, int t_first, int t_last,
-    double const *U, double *X, int ldx, int ncols, int m, int c_lo, int c_hi)
-{
-    using namespace sn;
-    int const adv = ws_ - 1 - 3 * nbc, gap = divceil(ws_ + adv, adv);
-    int const size = ihi - ilo, spc = (size <= ws_) ? 1 : divceil(size - ws_, adv) + 1;
-    SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbc * chains, spc, 0, 0, 0};
-    if (!agg_geometry_ok(step)) return -1;
-    std::vector<SweepStep> steps;
-    std::vector<size_t> uoff;
-    size_t nfac = 0;
-    for (int t = t_first; t <= t_last; t++) {
-        int cmin = (t - spc + 1 + gap - 1) / gap;
-        if (t - spc + 1 <= 0) cmin = 0;
-        int const cmax = std::min(chains - 1, t / gap);
-        if (cmax < cmin) continue;
-        step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
-        steps.push_back(step); uoff.push_back(nfac); nfac += step.ntasks;
-    }
-    double *dU, *dX, *dG; AggTile *dT;
-    SN_HIP_CHECK(hipMalloc((void **)&dU, std::max<size_t>(1, nfac) * 96 * 96 * 8));
-    SN_HIP_CHECK(hipMemcpy(dU, U, nfac * 96 * 96 * 8, hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipMalloc((void **)&dX, (size_t)ldx * ncols * 8));
-    SN_HIP_CHECK(hipMemcpy(dX, X, (size_t)ldx * ncols * 8, hipMemcpyHostToDevice));
-    AggPlan plan;
-    agg_plan(steps, [&](size_t i) { return (double const *)(dU + uoff[i] * 96 * 96); }, [&](size_t) { return m; }, plan);
-    int const ntiles = (int)plan.tiles.size();
-    SN_HIP_CHECK(hipMalloc((void **)&dG, std::max<size_t>(1, ntiles) * AGG_W * AGG_W * 8));
-    SN_HIP_CHECK(hipMalloc((void **)&dT, std::max<size_t>(1, ntiles) * sizeof(AggTile)));
-    for (int k = 0; k < ntiles; k++) plan.tiles[k].G = dG + (size_t)k * AGG_W * AGG_W;
-    SN_HIP_CHECK(hipMemcpy(dT, plan.tiles.data(), ntiles * sizeof(AggTile), hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipFuncSetAttribute((const void *)agg_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AGG_BUILD_LDS));
-    agg_set_attributes();
-    if (ntiles > 0) hipLaunchKernelGGL(agg_build_kernel, dim3(AGG_W / AGG_SLAB, ntiles), dim3(256), AGG_BUILD_LDS, nullptr, dT);
-    for (size_t v = 0; v + 1 < plan.wave_begin.size(); v++) {
-        int const b = plan.wave_begin[v], e = plan.wave_begin[v + 1];
-        int maxW = 0;
-        for (int k = b; k < e; k++) maxW = std::max(maxW, plan.tiles[k].W);
-        if (mode == 0) agg_launch_right(nullptr, maxW, divceil(m, AGG_BM), e - b, dT + b, dX, ldx, m, 0);
-        else agg_launch_left(nullptr, maxW, divceil(c_hi - c_lo, AGG_BM), e - b, dT + b, dX, ldx, c_lo, c_hi);
-    }
-    SN_HIP_CHECK(hipDeviceSynchronize());
-    SN_HIP_CHECK(hipMemcpy(X, dX, (size_t)ldx * ncols * 8, hipMemcpyDeviceToHost));
-    SN_HIP_CHECK(hipFree(dU)); SN_HIP_CHECK(hipFree(dX)); SN_HIP_CHECK(hipFree(dG)); SN_HIP_CHECK(hipFree(dT));
-    return ntiles;
-}
-
-// ---- test hook (tests/test_schur_agg_plan.py, no GPU needed): the tiling of agg_plan for the window
-// steps t_first..t_last of a sweep.  out[3 i .. 3 i + 2] = (tile, wavefront, window start) of the i-th
-// factor in issue order; returns the number of factors, < 0 if the geometry is not aggregated.
-extern "C" __attribute__((visibility("default")))
-int sn_internal_agg_plan(int ilo, int ihi, int ws_, int nbc, int chains, int t_first, int t_last, int *out, int cap,
-    int lu, int lc)
-{
-    using namespace sn;
-    int const adv = ws_ - 1 - 3 * nbc;
-    if (adv <= 0) return -1;
-    int const gap = divceil(ws_ + adv, adv);
-    int const size = ihi - ilo, spc = (size <= ws_) ? 1 : divceil(size - ws_, adv) + 1;
-    SweepStep step{ilo, ihi, ws_, nbc, adv, gap, nbc * chains, spc, 0, 0, 0};
-    if (!agg_geometry_ok(step)) return -1;
-    std::vector<SweepStep> steps;
-    std::vector<size_t> uoff;
-    size_t nfac = 0;
-    for (int t = t_first; t <= t_last; t++) {
-        int cmin = (t - spc + 1 + gap - 1) / gap;
-        if (t - spc + 1 <= 0) cmin = 0;
-        int const cmax = std::min(chains - 1, t / gap);
-        if (cmax < cmin) continue;
-        step.t = t; step.cmin = cmin; step.ntasks = cmax - cmin + 1;
-        steps.push_back(step); uoff.push_back(nfac); nfac += step.ntasks;
-    }
-    if ((int)nfac > cap) return -2;
-    AggPlan plan;
-    // the "address" of a factor is its issue index: the plan hands it back in AggFactor::U
-    double const *base = nullptr;
-    if (lu * lc > AGG_MAXF) return -3;
-    agg_plan(steps, [&](size_t i) { return base + uoff[i] * 96 * 96; }, [&](size_t) { return 0; }, plan,
-        lu > 0 ? lu : AGG_LU, lc > 0 ? lc : AGG_LC);
-    for (size_t v = 0; v + 1 < plan.wave_begin.size(); v++)
-        for (int k = plan.wave_begin[v]; k < plan.wave_begin[v + 1]; k++) {
-            AggTile const &t = plan.tiles[k];
-            for (int i = 0; i < t.nfac; i++) {
-                size_t const idx = (size_t)(t.f[i].U - base) / (96 * 96);
-                out[3 * idx] = k; out[3 * idx + 1] = (int)v; out[3 * idx + 2] = t.col0 + t.f[i].off;
-            }
-        }
-    return (int)nfac;
-}
-
-// ---- measurement hook (scratch/agg_bench.py): one wavefront of `ntiles` aggregated tiles (W columns each,
-// disjoint) applied to `rows` rows, alone on the GPU; mode 0: X <- X G, mode 1: X <- G^T X on `rows` columns.
-// Returns microseconds per launch.
-extern "C" __attribute__((visibility("default")))
-double sn_internal_agg_bench(int mode, int rows, int ntiles, int W, int reps)
-{
-    using namespace sn;
-    int const ld = (int)roundup(mode == 0 ? rows : ntiles * W, 16);
-    int const ncols = mode == 0 ? ntiles * W : rows;
-    double *X, *G; AggTile *dT;
-    SN_HIP_CHECK(hipMalloc((void **)&X, (size_t)ld * ncols * 8));
-    SN_HIP_CHECK(hipMalloc((void **)&G, (size_t)ntiles * AGG_W * AGG_W * 8));
-    SN_HIP_CHECK(hipMalloc((void **)&dT, ntiles * sizeof(AggTile)));
-    lcg_fill(nullptr, mode == 0 ? rows : ntiles * W, ncols, 7u, 1, X, ld);
-    std::vector<AggTile> t(ntiles);
-    for (int k = 0; k < ntiles; k++) {
-        t[k] = AggTile{}; t[k].G = G + (size_t)k * AGG_W * AGG_W; t[k].col0 = k * W; t[k].W = W; t[k].nfac = 0; t[k].rs = rows;
-        set_matrix(nullptr, AGG_W, AGG_W, 0.0, 1.0, t[k].G, AGG_W);
-    }
-    SN_HIP_CHECK(hipMemcpy(dT, t.data(), ntiles * sizeof(AggTile), hipMemcpyHostToDevice));
-    agg_set_attributes();
-    hipEvent_t e0, e1; SN_HIP_CHECK(hipEventCreate(&e0)); SN_HIP_CHECK(hipEventCreate(&e1));
-    double total = 0.0;
-    for (int r = 0; r < reps + 1; r++) {
-        SN_HIP_CHECK(hipEventRecord(e0, nullptr));
-        if (mode == 0) agg_launch_right(nullptr, W, divceil(rows, AGG_BM), ntiles, dT, X, ld, rows, 0);
-        else agg_launch_left(nullptr, W, divceil(rows, AGG_BM), ntiles, dT, X, ld, 0, rows);
-        SN_HIP_CHECK(hipEventRecord(e1, nullptr));
-        SN_HIP_CHECK(hipEventSynchronize(e1));
-        float ms; SN_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0) total += ms;
-    }
-    SN_HIP_CHECK(hipFree(X)); SN_HIP_CHECK(hipFree(G)); SN_HIP_CHECK(hipFree(dT));
-    return total / reps * 1e3;
-}
-
 // ---- measurement hook (NOT part of the public C-ABI; scratch/chase_bench.py): average duration
 // of one schur_chase_kernel launch with `chains` full windows on a random Hessenberg matrix
 extern "C" __attribute__((visibility("default")))

@@ -28,8 +28,9 @@ namespace sn { namespace host {
 
 // ---- helper threads of the sequential window kernels (schur_host_team.h) -----------------------
 namespace {
-Team &team() { static Team t; return t; }
-bool g_helpers_on = false;
+// (per calling thread: every device thread of the in-process multi-GPU path reduces its own replica)
+Team &team() { static thread_local Team t; return t; }
+thread_local bool g_helpers_on = false;
 } // namespace
 
 // Opens / closes a helper session (schur_device brackets a reduction with it when the node has

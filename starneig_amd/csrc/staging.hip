@@ -50,7 +50,8 @@ struct Stager {
         }
         lanes = 0;
     }
-} g_stager;
+};
+thread_local Stager g_stager;      // per host thread (one per device in the in-process multi-GPU path)
 
 // columns [c0, c1) of a rows x cols matrix, chunk by chunk through the lane's two slots
 void lane_copy(Lane &l, int device, bool to_device, double *dev, int ldd, double *host, int ldh,

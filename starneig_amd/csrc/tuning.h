@@ -21,11 +21,11 @@ struct Tuning {
     bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
     bool aed_profile = false;       // SN_AED_PROFILE
-    int schur_aggregate = 0;        // SN_SCHUR_AGG: 1 = aggregated lazy updates of H and Q (schur_agg.h), 2 = of Q only, 0 = off
     bool schur_hs_prio = true;      // SN_SCHUR_HS_PRIO=0: lazy H stream at the priority of the lazy Q stream (else one level above)
     int schur_cumask = 0;           // SN_SCHUR_CUMASK: CUs kept free of the lazy update streams (0 = no mask)
     // GEMM
     bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)
+    bool gemm_nosplit = false;      // SN_GEMM_NOSPLIT: whole tiles in the last round of workgroups too
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL

@@ -29,10 +29,10 @@ Tuning const &tuning()
         t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
         t.schur_profile = getb("SN_SCHUR_PROFILE");
         t.aed_profile = getb("SN_AED_PROFILE");
-        t.schur_aggregate = geti("SN_SCHUR_AGG", t.schur_aggregate);
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);
         t.schur_hs_prio = geti("SN_SCHUR_HS_PRIO", 1) != 0;
         t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
+        t.gemm_nosplit = getb("SN_GEMM_NOSPLIT");
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
         t.gep_serial = getb("SN_GEP_SERIAL");
         t.gep_reuse = std::max(1, std::min(8, geti("SN_GEP_REUSE", 1)));
