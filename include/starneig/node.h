@@ -1,8 +1,10 @@
 /* Library life cycle.  Replaces: reference src/include/starneig/node.h:72-220
  * (implementation common/node.c:435-650).  There is no StarPU underneath:
- * "cores" is kept for interface compatibility (host threads used by the
- * scheduler's helper work), "gpus" selects how many MI355X devices of this
- * process are used (1 per process; multi-GPU runs are one process per GPU). */
+ * "cores" = host threads the library may use (staging copies, the helper team of
+ * the host window kernels); "gpus" = how many MI355X devices of the node THIS
+ * process drives, min(gpus, devices present) like common/node.c:200-216, one host
+ * thread per device (csrc/node_team.hip): with more than one,
+ * starneig_SEP_SM_Hessenberg / _Schur run sharded over them. */
 #ifndef STARNEIG_AMD_NODE_H
 #define STARNEIG_AMD_NODE_H
 #ifdef __cplusplus
@@ -33,7 +35,8 @@ void starneig_node_set_cores(int cores);         /* node.h:200 */
 int  starneig_node_get_gpus(void);               /* node.h:207 */
 void starneig_node_set_gpus(int gpus);           /* node.h:214 */
 void starneig_node_finalize(void);               /* node.h:220 */
-/* node.h:234-241: pin the caller's arrays for the H2D/D2H at the boundary. */
+/* node.h:234-241.  Accepted, no effect: host arrays always travel through the
+ * library's own pinned staging slots (csrc/staging.hip). */
 void starneig_node_enable_pinning(void);
 void starneig_node_disable_pinning(void);
 

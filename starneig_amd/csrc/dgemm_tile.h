@@ -250,20 +250,42 @@ void gemm_tile(int m, int n, int k, double alpha,
             }
         return;
     }
-    #pragma unroll
-    for (int ci = 0; ci < Cfg::TN; ci++) {
-        double old[Cfg::TM][4];
-        if (beta != 0.0) {
+    if (beta != 0.0 && !atomic) {
+        // C <- alpha * sum + beta * C: the old values of column group ci + 1 are requested BEFORE group ci
+        // is stored (the groups are different columns), so the epilogue costs one memory latency, not
+        // one per group; the loads are unconditional from clamped addresses (a predicated load makes
+        // the compiler wait for every earlier one: see load_tiles)
+        double old[2][Cfg::TM][4];
+        auto fetch = [&](int ci, double (&o)[Cfg::TM][4]) {
             #pragma unroll
             for (int ri = 0; ri < Cfg::TM; ri++) {
-                int r = r0 + wm * Cfg::WM + ri * 16 + l15;
+                int const r = min(r0 + wm * Cfg::WM + ri * 16 + l15, m - 1);
                 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
-                    int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
-                    old[ri][reg] = (r < m && c < n) ? C[(size_t)c * ldc + r] : 0.0;
+                    int const c = min(c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg, n - 1);
+                    o[ri][reg] = C[(size_t)c * ldc + r];
+                }
+            }
+        };
+        fetch(0, old[0]);
+        #pragma unroll
+        for (int ci = 0; ci < Cfg::TN; ci++) {
+            if (ci + 1 < Cfg::TN) fetch(ci + 1, old[(ci + 1) & 1]);
+            #pragma unroll
+            for (int ri = 0; ri < Cfg::TM; ri++) {
+                int const r = r0 + wm * Cfg::WM + ri * 16 + l15;
+                #pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    int const c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
+                    if (tile_full || (r < m && c < n))
+                        C[(size_t)c * ldc + r] = alpha * acc[ci][ri][reg] + beta * old[ci & 1][ri][reg];
                 }
             }
         }
+        return;
+    }
+    #pragma unroll
+    for (int ci = 0; ci < Cfg::TN; ci++) {
         #pragma unroll
         for (int ri = 0; ri < Cfg::TM; ri++) {
             int r = r0 + wm * Cfg::WM + ri * 16 + l15;
@@ -272,9 +294,8 @@ void gemm_tile(int m, int n, int k, double alpha,
                 int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
                 if (r < m && c < n) {
                     double v = alpha * acc[ci][ri][reg];
-                    if (atomic) { atomicAdd(&C[(size_t)c * ldc + r], v); continue; }    // split-K slice
-                    if (beta != 0.0) v += beta * old[ri][reg];
-                    C[(size_t)c * ldc + r] = v;
+                    if (atomic) atomicAdd(&C[(size_t)c * ldc + r], v);      // split-K slice
+                    else C[(size_t)c * ldc + r] = v;
                 }
             }
         }

@@ -138,10 +138,10 @@ __global__ __launch_bounds__(64) void ht_qr_tfactor_kernel(int nb, double const 
 // ---------------------------------------------------------------------------------------------
 // Rotation step
 // ---------------------------------------------------------------------------------------------
-constexpr int HG = 4;              // waves of the chain workgroup that hold the rows of the group
+constexpr int HG = 8;              // waves of the chain workgroup that hold the rows of the group
 constexpr int HF = 0;               // follower waves: the 64*HF rows above the group
 constexpr int HGR = 64 * HG;        // rows of one diagonal group
-constexpr int HGR_MAX = 256;
+constexpr int HGR_MAX = 512;
 static_assert(HGR <= HGR_MAX, "the LDS column pass holds one group");
 
 typedef double v2d __attribute__((ext_vector_type(2)));

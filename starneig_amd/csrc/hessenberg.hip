@@ -8,7 +8,9 @@
 // Per panel column j (global pivot row piv = i+1+j) the dependent chain is three
 // launches:
 //   colA(j) : finish Y(:,j-1) = tau (y - Y w_v) from the gemv partials (cpu.c:253-270),
-//             p' = P(:,j) - Y V(piv-1,:)^T (cpu.c:98-99), w = (V T)^T p' (cpu.c:109-120)
+//             p' = P(:,j) - Y V(piv-1,:)^T (cpu.c:98-99), w = (V T)^T p' (cpu.c:109-120); the two
+//             products with the columns of Y that exist before gemv(j-1) are formed in that launch's
+//             shadow, not here
 //   colC(j) : p'' = p' - V w (cpu.c:123-130), ||p''(piv+1:)||^2, V^T p''  (for w_v)
 //   gemv(j) : y = A(i+1:end, piv:end) v  -- THE HBM-bound kernel (cpu.c:217-219,
 //             cuda.cu:62-107): every trailing element is streamed once per column;
@@ -157,82 +159,40 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
     }
 }
 
-// colA(j), j >= 1.
+// colA(j), j >= 1.  The two products with the OLD columns of Y that this step needs,
+//   t1 = Y(:,0:j-1) w_v   (for Y(:,j-1) = tau (y - t1), cpu.c:267-270)  and
+//   t2 = Y(:,0:j-1) V(piv-1,0:j-1)^T   (for p' = P(:,j) - Y V(piv-1,:)^T, cpu.c:98-99),
+// depend on nothing that gemv(j-1) computes: its shadow blocks form them while the trailing matrix
+// streams (a pass over the m x j panel factor Y that used to sit on the column chain).  What is left
+// here: one round of loads, the new column of Y, p', and w = (V T)^T p'.
 __global__ __launch_bounds__(CT)
 void hess_colA_kernel(int R0, int E, int j, int ldp,
-    double *__restrict__ P, double const *__restrict__ V, double const *__restrict__ VT,
+    double *__restrict__ P, double const *__restrict__ VT,
     double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
-    double *__restrict__ acc, double const *__restrict__ scal)
+    double const *__restrict__ t12, double *__restrict__ acc, double const *__restrict__ scal)
 {
-    __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_p[RB], s_y[NG - 1][RB], s_pp[NG - 1][RB], s_scal[3];
+    __shared__ double s_p[RB], s_scal[3];
     int const tid = threadIdx.x;
     int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
-    int const pivprev = R0 + j - 1, parp = (j - 1) & 1, par = j & 1;
+    int const pivprev = R0 + j - 1, par = j & 1;
     // scalars of column j-1 as published by gemv(j-1): P(piv-1, j-1) itself is overwritten
     // with beta by one block of THIS launch, so it must not be re-read here
-    // Everything this launch needs from memory that does not depend on anything computed here is
-    // requested in ONE round, in front of the first barrier: the scalars, row piv-1 of V with the slot
-    // sums, the gemv partials of this thread's row and its entry of column j (each of these used to be a
-    // round trip of its own on the column chain; the arithmetic and its order are unchanged).
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
-    constexpr int LPT = (MAXJ + CT - 1) / CT;
-    double vr_[LPT], ss_[LPT];
-    #pragma unroll
-    for (int q = 0; q < LPT; q++) {
-        int const l = tid + q * CT;
-        vr_[q] = l < j ? V[(size_t)l * ldp + pivprev] : 0.0;          // V(piv-1, l); = 1 for l = j-1
-        ss_[q] = l < j - 1 ? slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l) : 0.0;
+    double ysum = 0.0, pj = 0.0, t1 = 0.0, t2 = 0.0;
+    if (h == 0 && g < E) {
+        ysum = split_sum(ypart, ldp, g, nsplit); pj = P[(size_t)j * ldp + g];
+        t1 = t12[g]; t2 = t12[ldp + g];
     }
-    double ysum_early = 0.0, pj_early = 0.0;
-    if (h == 0 && g < E) { ysum_early = split_sum(ypart, ldp, g, nsplit); pj_early = P[(size_t)j * ldp + g]; }
-    __syncthreads();
-    {
-        double const scale = s_scal[0];
-        #pragma unroll
-        for (int q = 0; q < LPT; q++) {
-            int const l = tid + q * CT;
-            if (l < j) { s_vrow[l] = vr_[q]; s_wv[l] = (l < j - 1) ? vr_[q] + scale * ss_[q] : 0.0; }
-        }
-    }
-    __syncthreads();
-    double yacc = 0.0, pacc = 0.0;
-    if (g < E) {
-        double const *yrow = Y + g;
-        int l = h;
-        for (; l + 7 * NG < j - 1; l += 8 * NG) {       // 8 loads in flight: the loop is latency-bound
-            double y[8];
-            #pragma unroll
-            for (int q = 0; q < 8; q++) y[q] = yrow[(size_t)(l + q * NG) * ldp];
-            #pragma unroll
-            for (int q = 0; q < 8; q++) { yacc += y[q] * s_wv[l + q * NG]; pacc += y[q] * s_vrow[l + q * NG]; }
-        }
-        for (; l + 3 * NG < j - 1; l += 4 * NG) {
-            double y0 = yrow[(size_t)(l + 0 * NG) * ldp], y1 = yrow[(size_t)(l + 1 * NG) * ldp];
-            double y2 = yrow[(size_t)(l + 2 * NG) * ldp], y3 = yrow[(size_t)(l + 3 * NG) * ldp];
-            yacc += y0 * s_wv[l] + y1 * s_wv[l + NG] + y2 * s_wv[l + 2 * NG] + y3 * s_wv[l + 3 * NG];
-            pacc += y0 * s_vrow[l] + y1 * s_vrow[l + NG] + y2 * s_vrow[l + 2 * NG] + y3 * s_vrow[l + 3 * NG];
-        }
-        for (; l < j - 1; l += NG) {
-            double y0 = yrow[(size_t)l * ldp];
-            yacc += y0 * s_wv[l];
-            pacc += y0 * s_vrow[l];
-        }
-    }
-    if (h > 0) { s_y[h - 1][r] = yacc; s_pp[h - 1][r] = pacc; }
     __syncthreads();
     if (h == 0) {
         double pval = 0.0;
         if (g < E) {
             double const tau = s_scal[1], beta = s_scal[2];
-            #pragma unroll
-            for (int q = 0; q < NG - 1; q++) { yacc += s_y[q][r]; pacc += s_pp[q][r]; }
-            double const ysum = ysum_early;
-            double ynew = tau * (ysum - yacc);                 // cpu.c:267-270
+            double const ynew = tau * (ysum - t1);             // cpu.c:267-270
             Y[(size_t)(j - 1) * ldp + g] = ynew;
-            pacc += ynew * s_vrow[j - 1];
-            pval = pj_early - pacc;                            // cpu.c:98-99
+            pval = pj - (t2 + ynew);                           // cpu.c:98-99; V(piv-1, j-1) = 1
             P[(size_t)j * ldp + g] = pval;
             // column j-1 of P is final: beta on the sub-diagonal, zeros below (cpu.c:153-154)
             if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
@@ -364,10 +324,11 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double const *__restrict__ P, int R0, int E, int j, int cols_per_split, int ldp,
     int nshadow, int row_tiles,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
+    double const *__restrict__ Y, double *__restrict__ t12,
     double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
     double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr)
 {
-    __shared__ double s_wv[MAXJ], s_t[NGS][RBS + 1], s_scal[2];
+    __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_t[3][NGS][RBS + 1], s_scal[2];
     __shared__ int s_last;
     int const piv = R0 + j, par = j & 1;
     double const *__restrict__ pcol = P + (size_t)j * ldp;
@@ -387,33 +348,48 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
         int const tid = threadIdx.x;
         int const r = tid & (RBS - 1), h = tid / RBS;
         int const g = R0 + blockIdx.x * RBS + r;
-        for (int l = tid; l < j; l += 256)
-            s_wv[l] = V[(size_t)l * ldp + piv]
-                + scale * slot_sum(acc + ACC_WVSUM + par * NSLOT * MAXJ, l);
+        for (int l = tid; l < j; l += 256) {
+            double const vr = V[(size_t)l * ldp + piv];                 // V(piv, l)
+            s_vrow[l] = vr;
+            s_wv[l] = vr + scale * slot_sum(acc + ACC_WVSUM + par * NSLOT * MAXJ, l);
+        }
         __syncthreads();
         if (blockIdx.x == 0) {
             for (int l = tid; l < NSLOT * MAXJ; l += 256)
                 acc[ACC_WVSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
             if (tid < NSLOT) acc[ACC_NRM + (par ^ 1) * NSLOT + tid] = 0.0;
         }
-        double a = 0.0;
+        // a = VT(g, 0:j) w_v (for the new column of VT); ya = Y(g, 0:j) w_v and pa = Y(g, 0:j) V(piv, 0:j)^T:
+        // the two products colA(j+1) needs from the columns of Y that exist already (see colA)
+        double a = 0.0, ya = 0.0, pa = 0.0;
         if (g < E) {
-            double const *row = VT + g;
+            double const *row = VT + g, *yrow = Y + g;
             int l = h;
-            for (; l + 3 * NGS < j; l += 4 * NGS)
-                a += row[(size_t)(l + 0 * NGS) * ldp] * s_wv[l] + row[(size_t)(l + 1 * NGS) * ldp] * s_wv[l + NGS]
-                   + row[(size_t)(l + 2 * NGS) * ldp] * s_wv[l + 2 * NGS] + row[(size_t)(l + 3 * NGS) * ldp] * s_wv[l + 3 * NGS];
-            for (; l < j; l += NGS) a += row[(size_t)l * ldp] * s_wv[l];
+            // (two columns per trip, four loads in flight: with more the kernel leaves the 64 VGPRs that let
+            // eight waves of its STREAMING blocks share a SIMD -- measured: 80 VGPRs cost the gemv 4 %)
+            for (; l + NGS < j; l += 2 * NGS) {
+                double const x0 = row[(size_t)l * ldp], x1 = row[(size_t)(l + NGS) * ldp];
+                double const y0 = yrow[(size_t)l * ldp], y1 = yrow[(size_t)(l + NGS) * ldp];
+                a += x0 * s_wv[l] + x1 * s_wv[l + NGS];
+                ya += y0 * s_wv[l] + y1 * s_wv[l + NGS];
+                pa += y0 * s_vrow[l] + y1 * s_vrow[l + NGS];
+            }
+            for (; l < j; l += NGS) {
+                double const y0 = yrow[(size_t)l * ldp];
+                a += row[(size_t)l * ldp] * s_wv[l];
+                ya += y0 * s_wv[l]; pa += y0 * s_vrow[l];
+            }
         }
-        s_t[h][r] = a;
+        s_t[0][h][r] = a; s_t[1][h][r] = ya; s_t[2][h][r] = pa;
         __syncthreads();
         if (h == 0 && g < E) {
-            a = 0.0;
+            a = 0.0; ya = 0.0; pa = 0.0;
             #pragma unroll
-            for (int q = 0; q < NGS; q++) a += s_t[q][r];
+            for (int q = 0; q < NGS; q++) { a += s_t[0][q][r]; ya += s_t[1][q][r]; pa += s_t[2][q][r]; }
             double v = g < piv ? 0.0 : (g == piv ? 1.0 : scale * pcol[g]);
             V[(size_t)j * ldp + g] = v;
             VT[(size_t)j * ldp + g] = tau * (v - a);
+            t12[g] = ya; t12[ldp + g] = pa;
         }
         return;
     }
@@ -541,6 +517,7 @@ struct HessWorkspace {
     double *P = nullptr, *YVW[2] = {nullptr, nullptr}, *VT[2] = {nullptr, nullptr};
     double *S = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
+    double *t12 = nullptr;                      // [t1 | t2]: the products with the old columns of Y that colA(j+1) needs, formed in the shadow of gemv(j)
     static constexpr int MAX_ROW_TILES = 256;   // row tiles of a gemv launch (512 rows each): n <= 131072
     int *tile_cnt = nullptr;                    // sharded gemv: arrivals per row tile (self-resetting)
     hipStream_t side = nullptr, main = nullptr;
@@ -552,7 +529,7 @@ struct HessWorkspace {
     std::vector<double> sample_bytes;
 
     void release() {
-        double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal};
+        double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal, &t12};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         if (tile_cnt) { SN_HIP_CHECK(hipFree(tile_cnt)); tile_cnt = nullptr; }
         n = nbmax = 0; ysplits = 0;
@@ -576,6 +553,7 @@ struct HessWorkspace {
         alloc(&ypart, (size_t)ysplits * ldp * sizeof(double));
         alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
         alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
+        alloc(&t12, (size_t)2 * ldp * sizeof(double));
         SN_HIP_CHECK(hipMalloc((void **)&tile_cnt, sizeof(int) * MAX_ROW_TILES));
         SN_HIP_CHECK(hipMemset(tile_cnt, 0, sizeof(int) * MAX_ROW_TILES));
         if (!side) {
@@ -672,7 +650,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             int const piv = R0 + j;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, ws.P, V, VT, Y, ws.ypart, nsplit, ws.acc, ws.scal);
+                    R0, E, j, ldp, ws.P, VT, Y, ws.ypart, nsplit, ws.t12, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, ws.P, V, ws.acc);
             int const ncols = E - piv;
@@ -696,13 +674,13 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             long const cache_bytes = tuning().hess_cache_mb << 20;
             if (aligned && (long)m * ncols * 8 <= cache_bytes)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, false>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, Y, ws.t12, ws.acc, ws.scal, 1, -1);
             else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, Y, ws.t12, ws.acc, ws.scal, 1, -1);
             else
                 hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
-                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal, 1, -1);
+                    dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, Y, ws.t12, ws.acc, ws.scal, 1, -1);
             if (sampled) {
                 SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
                 ws.sample_bytes.push_back(8.0 * (double)m * (double)ncols);
@@ -907,7 +885,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             double const *ysrc = reduce_y ? dYsum : ws.ypart;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, dP, V, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.acc, ws.scal);
+                    R0, E, j, ldp, dP, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.t12, ws.acc, ws.scal);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, dP, V, ws.acc);
             // owned column blocks that intersect [piv, E): the splits of this rank's share of the gemv
@@ -921,15 +899,15 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             dim3 grid(nshadow + row_tiles * nsplit);
             if (aligned && reduce_y)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, true, true>), grid, dim3(256), 0, s,
-                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
                     world, rank, dYsum, ws.tile_cnt);
             else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
-                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
                     world, rank);
             else
                 hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
-                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, ws.acc, ws.scal,
+                    dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
                     world, rank);
             if (reduce_y) {
                 if (nsplit == 0) SN_HIP_CHECK(hipMemsetAsync(dYsum + R0, 0, (size_t)m * sizeof(double), s));
