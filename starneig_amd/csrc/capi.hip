@@ -95,6 +95,22 @@ void to_host(double *host, int ldh, double const *dev, int ldd, int n)
     sn::download_host_matrix(host, ldh, dev, ldd, n, n, g_node.cores);
 }
 
+// A problem that cannot fit the device is an error code, not an abort deep inside an allocation: `count`
+// n x n matrices of the caller plus the cached workspaces of the reduction (a generous 35 % of two
+// matrices plus 1 GB) against what the device has free right now, the library's own caches included.
+bool fits_device(int n, int count, char const *what)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
+    double const mat = (double)sn::roundup(n, 16) * n * sizeof(double);
+    double const need = count * mat + 0.7 * mat + 1e9;
+    if (need <= (double)free_b) return true;
+    if (g_node.messages)
+        fprintf(stderr, "[starneig-amd] %s: n = %d needs about %.1f GB of device memory, %.1f GB are free\n",
+            what, n, need / 1e9, (double)free_b / 1e9);
+    return false;
+}
+
 int default_panel_width(int n)          // hessenberg/interface.c:74-78
 {
     int a = (int)(0.001875596476 * n + 273.5908216);   // divceil(int,int), common/common.h:207
@@ -240,6 +256,7 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
         return sn::node_team_hessenberg(n, panel_width, A, ldA, Q, ldQ, g_node.cores) == 0
             ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 
+    if (!fits_device(n, 2, "starneig_SEP_SM_Hessenberg")) return STARNEIG_GENERIC_ERROR;
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dA = nullptr, *dQ = nullptr;
@@ -358,6 +375,7 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
         return sn::node_team_schur(n, H, ldH, Q, ldQ, real, imag, prm, g_node.cores);
     }
 
+    if (!fits_device(n, 2, "starneig_SEP_SM_Schur")) return STARNEIG_GENERIC_ERROR;
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dH = nullptr, *dQ = nullptr;
@@ -479,6 +497,7 @@ SN_API starneig_error_t starneig_SEP_SM_ReorderSchur_expert(
     int rc = reorder_params_from_conf(conf, window, vpc);
     if (rc != STARNEIG_SUCCESS) return rc;
 
+    if (!fits_device(n, 2, "starneig_SEP_SM_ReorderSchur")) return STARNEIG_GENERIC_ERROR;
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dS = nullptr, *dQ = nullptr;
@@ -577,6 +596,7 @@ SN_API starneig_error_t starneig_GEP_SM_Schur_expert(
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
+    if (!fits_device(n, 4, "starneig_GEP_SM_Schur")) return STARNEIG_GENERIC_ERROR;
     double *host[4] = {H, R, Q, Z};
     int const lds[4] = {ldH, ldR, ldQ, ldZ};
     double *dev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -630,6 +650,7 @@ SN_API starneig_error_t starneig_GEP_SM_HessenbergTriangular(
 
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
+    if (!fits_device(n, 4, "starneig_GEP_SM_HessenbergTriangular")) return STARNEIG_GENERIC_ERROR;
     double *host[4] = {A, B, Q, Z};
     int const lds[4] = {ldA, ldB, ldQ, ldZ};
     double *dev[4] = {nullptr, nullptr, nullptr, nullptr};

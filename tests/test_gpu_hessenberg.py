@@ -169,3 +169,20 @@ def test_baseline_sizes_properties(node, n):
     assert abs(tr0 - tr1) <= 1e-11 * abs(tr0)
     f0 = torch.linalg.norm(tA0[:, :n]).item(); f1 = torch.linalg.norm(tA[:, :n]).item()
     assert abs(f0 - f1) <= 1e-12 * f0
+
+
+def test_problem_larger_than_the_device_is_an_error_code_not_an_abort(node):
+    """two 200000 x 200000 matrices are 640 GB: the host-array entry points see that before they
+    allocate anything and return STARNEIG_GENERIC_ERROR (the arrays are never touched)"""
+    n = 200000
+    stub = np.zeros(16)
+    L = node.lib.load()
+    p = stub.ctypes.data
+    assert L.starneig_SEP_SM_Hessenberg(n, p, n, p, n) == node.GENERIC_ERROR
+    assert L.starneig_SEP_SM_Schur(n, p, n, p, n, None, None) == node.GENERIC_ERROR
+    # the library is still usable
+    m = 64
+    A0 = O.random_fullpos(m)
+    A = A0.copy(order="F"); Q = O.identity(m)
+    assert node.SEP_SM_Hessenberg(m, A, A.shape[0], Q, Q.shape[0]) == 0
+    assert O.residual_u(Q, A, A0) < 50
