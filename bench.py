@@ -241,11 +241,13 @@ def bench_ht(args):
 def cpu_baseline(n_lapack, n_port):
     """CPU baseline on this host's cores, on bounded samples of the same workload (smaller n,
     same LCG input, same flop conventions):
-      * top level, `kind: "port"`: the repo's CPU restatement of the reference algorithm (oracle/:
-        the reference's panel / column / update order in plain loops, OpenMP over the host cores,
-        for the Hessenberg leg; a one-thread double-shift QR -- the arithmetic of LAPACK dlahqr -- for
-        the Schur leg).  The reference's own StarPU build cannot be compiled here,
-        so there is no `kind: "reference"` number;
+      * top level, `kind: "port"`: the repo's multi-threaded CPU restatement of the reference algorithm
+        (oracle/hessenberg_oracle.c: the reference's panel / column / update order in plain loops under
+        OpenMP; oracle/msqr_port.c: small-bulge multishift QR with aggressive early deflation -- chains of
+        packed bulges chased through diagonal windows, the off-diagonal updates as threaded matrix
+        products, the AED window and small-block kernels taken from the product's host-only code).  The
+        reference's own StarPU build cannot be compiled here, so there is no
+        `kind: "reference"` number;
       * `lapack_comparator`: LAPACK dgehrd + dorghr + dhseqr("S","V") through scipy's OpenBLAS on all
         the threads it uses -- the comparator the reference's own test driver offers
         (test/hessenberg/solvers.c:231-283, test/schur/solvers.c:120-169), the arithmetic the
@@ -258,20 +260,30 @@ def cpu_baseline(n_lapack, n_port):
     cores = os.cpu_count() or 1
     if n_port > 0:
         import oracle as O
+        import starneig_amd as S
         nthr = min(cores, 64)
         os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
-        A = O.random_fullpos(n_port)
+        hooks = S.lib.load_test_hooks()         # host-only window kernels of the product (csrc/schur_host.hip)
+        A0 = O.random_fullpos(n_port)
+        A = A0.copy(order="F")
         Q = O.identity(n_port)
         t0 = time.perf_counter()
         O.hessenberg(A, Q)
         t1 = time.perf_counter()
-        O.schur(A, Q)
+        rc, wr, wi, st = O.msqr_port(A, Q, hooks.sn_internal_aed_window, hooks.sn_internal_small_schur)
         t2 = time.perf_counter()
+        assert rc == 0 and O.check_schur_form(A) == 0, "the CPU port did not produce a Schur form"
+        res = O.residual_u(Q, A, A0)
+        assert res < 500.0, f"CPU port residual {res} u"
         out.update({"value": (hess_flops(n_port) + schur_flops(n_port)) / (t2 - t0) / 1e9,
                     "cores": int(os.environ["OMP_NUM_THREADS"]),
-                    "sample": f"oracle restatement (oracle/hessenberg_oracle.c, schur_oracle.c) on the LCG matrix at "
-                              f"n={n_port}: Hessenberg {t1 - t0:.1f} s (OpenMP, {os.environ['OMP_NUM_THREADS']} threads), "
-                              f"Schur {t2 - t1:.1f} s (double-shift QR, 1 thread); flop conventions (16/3+25) n^3"})
+                    "sample": f"CPU restatement of the reference algorithm on the LCG matrix at n={n_port}, "
+                              f"{os.environ['OMP_NUM_THREADS']} OpenMP threads: Hessenberg {t1 - t0:.1f} s "
+                              f"(oracle/hessenberg_oracle.c: the reference's panel / column / update order), Schur "
+                              f"{t2 - t1:.1f} s (oracle/msqr_port.c: multishift QR with AED, {st['sweeps']} sweeps, "
+                              f"{st['aeds']} AED windows -- chains of packed bulges through diagonal windows, "
+                              f"off-diagonal updates as threaded matrix products; the window kernels are the product's "
+                              f"own host code); residual {res:.0f} u; flop conventions (16/3+25) n^3"})
     if n_lapack > 0:
         import scipy.linalg as sl
         from scipy.linalg import lapack
@@ -424,7 +436,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=4000,
                     help="size of the LAPACK CPU-baseline sample (0 = skip; n=4000 is ~30 s on the GPU box's host, "
                          "n=8000 ~4 min)")
-    ap.add_argument("--cpu-port-n", type=int, default=1500,
+    ap.add_argument("--cpu-port-n", type=int, default=3000,
                     help="size of the oracle-port CPU sample (0 = skip)")
     ap.add_argument("--host-api", type=int, default=1,
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")

@@ -69,6 +69,9 @@ def lib():
         L.oracle_decouple.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
         L.oracle_known_eigenvalues_check.argtypes = [C.c_int] + [dp] * 6 + [C.c_double, C.c_double, dp, ip]
         L.oracle_eigenvalues_check.argtypes = [C.c_int] + [dp] * 6 + [C.c_double, C.c_double, dp, ip]
+        L.oracle_msqr_port.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, dp]
+        L.oracle_msqr_port.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -379,3 +382,22 @@ def eigenvalues_check(extracted, returned, warn=1e3, fail=1e4):
     """The reference's `eigenvalues` hook (test/common/hooks.c:787-788,891-991): eigenvalues read
     off the diagonal blocks of the result against those the solver returned, by position."""
     return _hook(lib().oracle_eigenvalues_check, extracted, returned, warn, fail)
+
+
+# ---- CPU port of the multishift QR / AED Schur leg (oracle/msqr_port.c; bench.py's cpu_baseline) ----
+
+def msqr_port(H, Q, aed_fn, small_fn, nw=None, ns=None, W=128, small_limit=128):
+    """In place: the upper Hessenberg (ld, n) array H -> real Schur form, Q <- Q U, by the multi-threaded
+    host restatement of the reference's Schur leg.  aed_fn / small_fn: C function pointers of the AED window
+    kernel and the small-block solver (the host-only kernels of the product's test library).  Returns
+    (rc, real, imag, stats)."""
+    n = H.shape[1]
+    # the reference's defaults (schur/process_args.c:116-162 through LAPACK's iparmq table): here the
+    # window the host kernel is fastest at
+    nw = nw or min(n, max(64, min(288, 136 + int(0.006 * n))))
+    ns = ns or max(2, (nw * 5 // 8) // 2 * 2)
+    st = np.zeros(4)
+    rc = lib().oracle_msqr_port(n, _p(H), H.shape[0], _p(Q), Q.shape[0], nw, ns, W, small_limit,
+                                C.cast(aed_fn, C.c_void_p), C.cast(small_fn, C.c_void_p), _p(st))
+    wr, wi = extract_eigenvalues(H)
+    return rc, wr, wi, {"sweeps": int(st[0]), "aeds": int(st[1]), "update_flops": st[2], "aed_s": st[3]}

@@ -139,3 +139,21 @@ def test_dlanv2_known_answers():
     a, b, c, d, r1, i1, r2, i2, cs, sn = run(2.0, 1.0, 2.0, 3.0)
     assert c == 0.0 and i1 == 0.0 and sorted([round(r1, 12), round(r2, 12)]) == [1.0, 4.0]
     assert abs(cs * cs + sn * sn - 1.0) < 1e-15
+
+
+def test_multishift_port_of_the_schur_leg():
+    """oracle/msqr_port.c (bench.py's cpu_baseline): multishift QR with AED on the host, driving the
+    host-only window kernels of the product's test library -- a valid Schur decomposition with the
+    eigenvalues LAPACK finds"""
+    import starneig_amd as S
+    L = S.lib.load_test_hooks()
+    n = 500
+    A0 = O.random_fullpos(n)
+    H = A0.copy(order="F"); Q = O.identity(n)
+    O.hessenberg(H, Q)
+    rc, wr, wi, st = O.msqr_port(H, Q, L.sn_internal_aed_window, L.sn_internal_small_schur, nw=96, ns=60, W=64,
+                                 small_limit=64)
+    assert rc == 0 and st["sweeps"] > 0 and st["aeds"] > 0
+    assert O.check_schur_form(H) == 0
+    assert O.residual_u(Q, H, A0) < 500 and O.orthogonality_u(Q) < 500
+    assert O.match_eigenvalues(wr + 1j * wi, np.linalg.eigvals(A0[:n])) < 1e4
