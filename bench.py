@@ -261,7 +261,7 @@ def cpu_baseline(n_lapack, n_port):
     if n_port > 0:
         import oracle as O
         import starneig_amd as S
-        nthr = min(cores, 64)
+        nthr = min(cores, 32)                   # (plain-loop kernels on 128-row windows: more threads than this only add overhead)
         os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
         hooks = S.lib.load_test_hooks()         # host-only window kernels of the product (csrc/schur_host.hip)
         A0 = O.random_fullpos(n_port)

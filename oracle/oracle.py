@@ -63,7 +63,8 @@ def lib():
         L.oracle_hessenberg_triangular.restype = C.c_int
         L.oracle_lartg.argtypes = [C.c_double, C.c_double, dp, dp, dp]
         ip = C.POINTER(C.c_int)
-        L.oracle_known_spectrum.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp]
+        L.oracle_known_spectrum.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp, C.c_int]
+        L.oracle_uniform_select.argtypes = [C.c_int, dp, C.c_int, C.c_double, ip]
         L.oracle_place_blocks.argtypes = [C.c_int, dp, dp, dp, dp, C.c_int, dp, C.c_int]
         L.oracle_householder_vector.argtypes = [C.c_int, dp]
         L.oracle_decouple.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
@@ -320,7 +321,7 @@ def known_pencil(n, generalized=False, seed=2019, complex_ratio=0.5, zero_ratio=
         T = identity(n, ld)
     real, imag, beta = np.zeros(n), np.zeros(n), np.zeros(n)
     L.oracle_known_spectrum(n, int(generalized), complex_ratio, zero_ratio, inf_ratio,
-                            _p(real), _p(imag), _p(beta))
+                            _p(real), _p(imag), _p(beta), 0)
     L.oracle_place_blocks(n, _p(real), _p(imag), _p(beta), _p(S), ld,
                           _p(T) if generalized else None, ld)
     if generalized:
@@ -401,3 +402,23 @@ def msqr_port(H, Q, aed_fn, small_fn, nw=None, ns=None, W=128, small_limit=128):
                                 C.cast(aed_fn, C.c_void_p), C.cast(small_fn, C.c_void_p), _p(st))
     wr, wi = extract_eigenvalues(H)
     return rc, wr, wi, {"sweeps": int(st[0]), "aeds": int(st[1]), "update_flops": st[2], "aed_s": st[3]}
+
+
+def reorder_input(n, seed=2019, fortify=True, complex_ratio=0.5, select_ratio=0.35, ld=None):
+    """`starneig-test --experiment reorder [--fortify]` (test/common/init_schur.c:122-181): a random upper
+    triangular S with the blocks of `complex_distr uniform` on its diagonal (with --fortify: eigenvalues two
+    apart), Q a random Householder matrix, and the selection of `select_distr uniform` (35 % of the rows, whole
+    blocks).  Returns S, Q, selected (int32), and the prescribed eigenvalues (real, imag) in diagonal order."""
+    ld = ld or ld_for(n)
+    L = lib()
+    L.oracle_init_prand(seed)
+    S = np.zeros((ld, n), order="F")
+    L.oracle_fill_random_uptriag(n, _p(S), ld)
+    real, imag, beta = np.zeros(n), np.zeros(n), np.zeros(n)
+    L.oracle_known_spectrum(n, 0, complex_ratio, 0.01, 0.01, _p(real), _p(imag), _p(beta), int(fortify))
+    L.oracle_place_blocks(n, _p(real), _p(imag), _p(beta), _p(S), ld, None, ld)
+    Q, _ = householder_matrix(n, ld)
+    sel = np.zeros(n, dtype=np.int32)
+    L.oracle_uniform_select(n, _p(S), ld, select_ratio, sel.ctypes.data_as(C.POINTER(C.c_int)))
+    kr, ki = extract_eigenvalues(S)
+    return S, Q, sel, kr, ki

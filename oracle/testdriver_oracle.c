@@ -9,6 +9,8 @@
 //   * placement of the 1x1 / 2x2 blocks               test/common/block_placer.c:53-100
 //   * random Householder matrix                       test/common/init.c:173-191,523-541
 //   * `--decouple k` / `--set-to-inf k`                test/schur/experiment.c:66-140
+//   * the reorder experiment's input (`--fortify`) and `select_distr uniform`
+//                                                     test/common/init_schur.c:122-181, select_distr.c:48-143
 //   * the `known-eigenvalues` hook (greedy nearest match, warn 1e4 u, fail 1e6 u)
 //                                                     test/common/hooks.c:1071-1296
 //   * the `eigenvalues` hook (position by position, warn 1e3 u, fail 1e4 u)
@@ -26,14 +28,29 @@ static double squ(double x) { return x * x; }
 
 // uniform_complex_distr_init (complex_distr.c:144-228) without --fortify, followed by
 // generate_special_cases (:51-76).  `generalized` = "B != NULL" of the reference.
+// fortify != 0: `--fortify` (complex_distr.c:165-171, :186-196) -- eigenvalues 2 apart, "fortified against
+// failed swaps"; no special cases, no draws besides the placement of the 2x2 blocks.
 void oracle_known_spectrum(int n, int generalized, double complex_ratio, double zero_ratio,
-                           double inf_ratio, double *real, double *imag, double *beta)
+                           double inf_ratio, double *real, double *imag, double *beta, int fortify)
 {
     int complex_count = complex_ratio * n / 2;
     int real_count = n - 2 * complex_count;
     int *spaces = calloc(complex_count + 1, sizeof(int));
     for (int i = 0; i < real_count; i++)
         spaces[oracle_prand() % (complex_count + 1)]++;
+    if (fortify) {
+        for (int i = 0; i < n; i++) { real[i] = 2.0 * (i - n / 2 + 0.5); imag[i] = 0.0; beta[i] = 1.0; }
+        int i = 0;
+        for (int j = 0; j < complex_count; j++) {
+            i += spaces[j];
+            imag[i] = fabs(real[i]);
+            real[i + 1] = real[i];
+            imag[i + 1] = -imag[i];
+            i += 2;
+        }
+        free(spaces);
+        return;
+    }
     for (int i = 0; i < n; i++) {
         real[i] = (2.0 * oracle_prand() / PRAND_MAX - 1.0) * n;
         imag[i] = 0.0;
@@ -219,4 +236,21 @@ void oracle_eigenvalues_check(int n, const double *real1, const double *imag1, c
     out[0] = mean / n;
     out[1] = mn;
     out[2] = mx;
+}
+
+// uniform_select_distr_init (test/common/select_distr.c:48-60, :122-143): whole diagonal blocks drawn with
+// the LCG until `ratio` of the rows is selected.  A: the (quasi-)triangular matrix.
+void oracle_uniform_select(int n, const double *A, int ldA, double ratio, int *select)
+{
+    int *blocks = calloc(n, sizeof(int));
+    for (int i = 1; i < n; i++) blocks[i] = A[(size_t)(i - 1) * ldA + i] != 0.0;
+    for (int i = 0; i < n; i++) select[i] = 0;
+    int selected = 0;
+    while (selected < ratio * n) {
+        int const i = oracle_prand() % n;
+        if (select[i] || blocks[i]) continue;
+        select[i] = 1; selected++;
+        if (i + 1 < n && blocks[i + 1]) { select[i + 1] = 1; selected++; }
+    }
+    free(blocks);
 }

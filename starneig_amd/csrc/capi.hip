@@ -252,11 +252,11 @@ SN_API starneig_error_t starneig_SEP_SM_Hessenberg_expert(
     // several GPUs (starneig_node_init(cores, gpus > 1, ...)): the block-column sharded reduction, one
     // host thread per device (node_team.hip).  Partial ranges and matrices too small to shard stay on
     // one device.
+    if (!fits_device(n, 2, "starneig_SEP_SM_Hessenberg")) return STARNEIG_GENERIC_ERROR;
     if (g_node.gpus > 1 && begin == 0 && end == n && n >= 256 * g_node.gpus)
         return sn::node_team_hessenberg(n, panel_width, A, ldA, Q, ldQ, g_node.cores) == 0
             ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 
-    if (!fits_device(n, 2, "starneig_SEP_SM_Hessenberg")) return STARNEIG_GENERIC_ERROR;
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dA = nullptr, *dQ = nullptr;
@@ -370,12 +370,12 @@ SN_API starneig_error_t starneig_SEP_SM_Schur_expert(
     if (rc != STARNEIG_SUCCESS) return rc;
     prm.host_threads = g_node.cores;
 
+    if (!fits_device(n, 2, "starneig_SEP_SM_Schur")) return STARNEIG_GENERIC_ERROR;
     if (g_node.gpus > 1 && n >= 256 * g_node.gpus) {
         if (real == NULL || imag == NULL) real = imag = nullptr;
         return sn::node_team_schur(n, H, ldH, Q, ldQ, real, imag, prm, g_node.cores);
     }
 
-    if (!fits_device(n, 2, "starneig_SEP_SM_Schur")) return STARNEIG_GENERIC_ERROR;
     int const ld = (int)sn::roundup(n, 16);
     size_t const bytes = (size_t)ld * n * sizeof(double);
     double *dH = nullptr, *dQ = nullptr;

@@ -209,3 +209,124 @@ def test_check_device_against_independent_fp64(node, n):
     res, orth = torch_check(tQ, tH, tA0, n)
     print(f"n={n}: library {chk['residual_u']:.2f} / {chk['orthogonality_u']:.2f} u, torch {res:.2f} / {orth:.2f} u")
     assert rc == 0 and agree(res, chk["residual_u"]) and agree(orth, chk["orthogonality_u"]), (res, orth, chk)
+
+
+# ---------------------------------------------------------------------------------------------
+# (4) the "simple" CTest points (test/CMakeLists.txt:300-345): --n 5000 --solver starneig-simple,
+#     i.e. the plain host-array interface, for the experiments of this path
+# ---------------------------------------------------------------------------------------------
+
+def test_ctest_simple_hessenberg_n5000(node):
+    """simple-hessenberg: random full matrix (LCG), Q = I; hooks: Hessenberg form, residual"""
+    n = 5000
+    A0 = O.random_fullpos(n)
+    A = A0.copy(order="F"); Q = O.identity(n)
+    assert node.SEP_SM_Hessenberg(n, A, A.shape[0], Q, Q.shape[0]) == 0
+    assert O.count_below_subdiagonal(A) == 0
+    res, orth = torch_check(to_device(Q), to_device(A), to_device(A0), n)
+    print(f"simple-hessenberg: {res:.1f} / {orth:.1f} u")
+    assert res < 1.5 * 15 and orth < 1.5 * 11
+
+
+def test_ctest_simple_schur_n5000(node):
+    """simple-schur: random Hessenberg matrix, Q a random Householder matrix; hooks: Schur form,
+    eigenvalues, residual against Q0 H0 Q0^T"""
+    n = 5000
+    H0, Q0, _, _ = O.schur_random_input(n)
+    H = H0.copy(order="F"); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H, H.shape[0], Q, Q.shape[0], real, imag) == 0
+    assert O.check_schur_form(H) == 0
+    er, ei = O.extract_eigenvalues(H)
+    hook = O.eigenvalues_check((er, ei, np.ones(n)), (real, imag, np.ones(n)))
+    assert hook["failures"] == 0 and hook["warnings"] == 0, hook
+    tQ0, tH0 = to_device(Q0), to_device(H0)
+    import torch
+    tA0 = torch.zeros_like(tH0)
+    tA0[:, :n] = (tQ0[:, :n].T @ tH0[:, :n].T @ tQ0[:, :n]).T
+    res, orth = torch_check(to_device(Q), to_device(H), tA0, n)
+    print(f"simple-schur: {res:.1f} / {orth:.1f} u")
+    assert res < WARN_U and orth < WARN_U
+
+
+def test_ctest_simple_reorder_n5000(node):
+    """simple-reorder --fortify: a quasi-triangular S with eigenvalues two apart (half of them in 2 x 2
+    blocks), Q a random Householder matrix, 35 % of the rows selected by the driver's LCG.  The prescribed
+    spectrum is an exact oracle here: the leading block must carry exactly the selected eigenvalues."""
+    n = 5000
+    S0, Q0, sel, kr, ki = O.reorder_input(n)
+    k = int(sel.sum())
+    wanted = np.sort_complex(kr[sel == 1] + 1j * ki[sel == 1])
+    S = S0.copy(order="F"); Q = Q0.copy(order="F")
+    real = np.zeros(n); imag = np.zeros(n)
+    assert node.SEP_SM_ReorderSchur(n, sel, S, S.shape[0], Q, Q.shape[0], real, imag) == 0
+    assert O.check_schur_form(S) == 0
+    assert np.array_equal(sel, (np.arange(n) < k).astype(np.int32))
+    got = np.sort_complex(real[:k] + 1j * imag[:k])
+    assert np.abs(got - wanted).max() <= 1e4 * U * n          # eigenvalues up to n in modulus, 2 apart
+    import torch
+    tQ0, tS0 = to_device(Q0), to_device(S0)
+    tA0 = torch.zeros_like(tS0)
+    tA0[:, :n] = (tQ0[:, :n].T @ tS0[:, :n].T @ tQ0[:, :n]).T
+    res, orth = torch_check(to_device(Q), to_device(S), tA0, n)
+    print(f"simple-reorder: {k} selected, {res:.1f} / {orth:.1f} u")
+    # 1751 selected rows climb through ~2500 rows each: measured 493 u / 174 u.  The reference's residual hook
+    # warns above 500 u and fails above 10^4 u (test/common/hooks.c:52,57); twice the warn level here
+    assert res < 2 * WARN_U and orth < WARN_U
+
+
+def test_ctest_simple_full_chain_n5000(node):
+    """simple-full-chain: starneig_SEP_SM_Reduce(..., predicate = (0 < real), arg = NULL, selected = NULL,
+    &num_selected) on the random full matrix (test/misc/full_chain.c:203-240)"""
+    n = 5000
+    A0 = O.random_fullpos(n)
+    A = A0.copy(order="F"); Q = O.identity(n)
+    real = np.zeros(n); imag = np.zeros(n)
+    rc, sel, cnt = node.SEP_SM_Reduce(n, A, A.shape[0], Q, Q.shape[0], real, imag,
+                                      predicate=lambda re, im: re > 0.0)
+    assert rc == 0 and 0 < cnt < n
+    assert O.check_schur_form(A) == 0
+    assert np.all(real[:cnt] > 0.0) and np.all(real[cnt:] <= 0.0)
+    er, ei = O.extract_eigenvalues(A)
+    hook = O.eigenvalues_check((er, ei, np.ones(n)), (real, imag, np.ones(n)))
+    assert hook["failures"] == 0 and hook["warnings"] == 0, hook
+    res, orth = torch_check(to_device(Q), to_device(A), to_device(A0), n)
+    print(f"simple-full-chain: {cnt} selected, {res:.1f} / {orth:.1f} u")
+    assert res < WARN_U and orth < WARN_U
+    assert abs(real.sum() - np.trace(A0[:n])) <= 1e-9 * n * n
+
+
+def test_ctest_simple_generalized_n5000(node):
+    """simple-hessenberg-generalized and simple-schur-generalized: two random full matrices reduced to
+    Hessenberg-triangular form; a random Hessenberg-triangular pencil with Householder Q and Z reduced
+    to generalized Schur form -- both through the host-array interface"""
+    n = 5000
+    A0, B0 = O.random_fullpos_pair(n)
+    A, B = A0.copy(order="F"), B0.copy(order="F")
+    Q, Z = O.identity(n), O.identity(n)
+    assert node.GEP_SM_HessenbergTriangular(n, A, A.shape[0], B, B.shape[0], Q, Q.shape[0], Z, Z.shape[0]) == 0
+    assert O.count_below_subdiagonal(A) == 0 and O.count_below_diagonal(B) == 0
+    ra, oq, oz = torch_check_pencil(to_device(Q), to_device(A), to_device(Z), to_device(A0), n)
+    rb, _, _ = torch_check_pencil(to_device(Q), to_device(B), to_device(Z), to_device(B0), n)
+    print(f"simple-hessenberg-generalized: {ra:.1f} / {rb:.1f} u, {oq:.1f} / {oz:.1f} u")
+    assert max(ra, rb, oq, oz) < WARN_U
+    H0, Q0, R0, Z0 = O.schur_random_input(n, generalized=True)
+    H, R = H0.copy(order="F"), R0.copy(order="F")
+    Qs, Zs = Q0.copy(order="F"), Z0.copy(order="F")
+    ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+    assert node.GEP_SM_Schur(n, H, H.shape[0], R, R.shape[0], Qs, Qs.shape[0], Zs, Zs.shape[0], ar, ai, be) == 0
+    assert O.check_gep_schur_form(H, R) == 0
+    import torch
+    tQ0, tZ0 = to_device(Q0), to_device(Z0)
+    def original(M0):
+        t = to_device(M0)
+        out = torch.zeros_like(t)
+        out[:, :n] = (tQ0[:, :n].T @ t[:, :n].T @ tZ0[:, :n]).T        # (Q0 M0 Z0^T)^T = Z0 M0^T Q0^T
+        return out
+    ra, oq, oz = torch_check_pencil(to_device(Qs), to_device(H), to_device(Zs), original(H0), n)
+    rb, _, _ = torch_check_pencil(to_device(Qs), to_device(R), to_device(Zs), original(R0), n)
+    print(f"simple-schur-generalized: {ra:.1f} / {rb:.1f} u, {oq:.1f} / {oz:.1f} u")
+    assert max(ra, rb, oq, oz) < WARN_U
+    er, ei, eb = O.gep_extract_eigenvalues(H, R)
+    hook = O.eigenvalues_check((er, ei, eb), (ar, ai, be), warn=1e5, fail=1e6)   # (nearly real pairs: see tests/test_gpu_gep.py)
+    assert hook["failures"] == 0, hook
