@@ -436,7 +436,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=4000,
                     help="size of the LAPACK CPU-baseline sample (0 = skip; n=4000 is ~30 s on the GPU box's host, "
                          "n=8000 ~4 min)")
-    ap.add_argument("--cpu-port-n", type=int, default=3000,
+    ap.add_argument("--cpu-port-n", type=int, default=2500,
                     help="size of the oracle-port CPU sample (0 = skip)")
     ap.add_argument("--host-api", type=int, default=1,
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")

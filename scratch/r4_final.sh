@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-4 final validation: smoke, the whole GPU suite, the default bench line
+cd "$GRAFT_REPO_ROOT"
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r4_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/r4_smoke.log
+tail -2 gpurun_out/r4_smoke.log
+timeout 2400 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/r4_gpu_tests.log 2>&1
+tail -18 gpurun_out/r4_gpu_tests.log
+( time python bench.py ) > gpurun_out/r4_bench_line.json 2> gpurun_out/r4_bench_line.err
+tail -4 gpurun_out/r4_bench_line.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r4_bench_line.json").read().strip().splitlines()[-1])
+print(d["ms_per_step"], d["value"], d["roofline"]["frac"], d["roofline_mfma"]["frac"], d["roofline_mfma"]["critical_update_frac"])
+print(d["cpu_baseline"]["value"], d["cpu_baseline"]["sample"][:200])
+PY

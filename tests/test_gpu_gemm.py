@@ -61,3 +61,22 @@ def test_dgemm_identity_asymmetric(node):
     assert np.array_equal(to_host(tC), B)
     node.dgemm_device("T", "T", n, n, n, 1.0, to_device(B), n, to_device(I), n, 0.0, tC, n)
     assert np.array_equal(to_host(tC), B.T)
+
+
+@pytest.mark.parametrize("m,n", [(3000, 3000), (4200, 4200), (3300, 3300), (2900, 4500), (3007, 3001)])
+def test_big_tile_launch_with_a_cut_last_round(node, m, n):
+    """128 x 128 launches of more than 512 tiles cut the tiles of their last, partly filled round of
+    workgroups into halves or quarters (csrc/dgemm_mfma.hip): 576 tiles -> 64 quartered, 1089 -> 65
+    quartered, 676 -> 164 halved, 828 -> whole tiles, and one odd size.  Against torch.matmul in fp64."""
+    import torch
+    k = 312
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n)
+    A = torch.rand((k, m), dtype=torch.float64, device="cuda", generator=g) - 0.5       # column-major m x k
+    B = torch.rand((k, n), dtype=torch.float64, device="cuda", generator=g) - 0.5       # column-major n x k
+    C0 = torch.rand((n, m), dtype=torch.float64, device="cuda", generator=g) - 0.5      # column-major m x n
+    C = C0.clone()
+    assert node.dgemm_device("N", "T", m, n, k, -1.0, A, m, B, n, 1.0, C, m) == 0
+    torch.cuda.synchronize()
+    ref = C0 - B.T @ A                  # (A_cm B_cm^T)^T = B_t^T A_t in the tensors' layout
+    bound = (torch.abs(B).T @ torch.abs(A)) * 4 * k * U + torch.abs(C0) * 2 * U
+    assert bool((torch.abs(C - ref) <= bound).all())
