@@ -82,6 +82,19 @@ starneig_error_t starneig_amd_schur_rows_device(
     int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, double *real, double *imag,
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
+/* The same with the left updates of the DEFLATED columns of H sharded as well: those columns (right of
+ * the active block) are never read or mixed by a later window, they only receive further left updates,
+ * column by column.  Rank r of `world` keeps the 128-column tiles T (columns [128 T, 128 T + 128)) with
+ * T % world == r up to date and skips the others -- still no communication during the reduction.  On
+ * return column tile T of the Schur form is valid on rank T % world only (the diagonal blocks, the
+ * eigenvalues and everything left of them are valid everywhere); the caller assembles H from the
+ * owners' tiles (starneig_amd/distributed.py: one broadcast per tile; node_team.hip: every rank copies
+ * its tiles back).  What the reference does by moving tiles between workers (schur/core.c:129-460
+ * insert_updates over StarPU-MPI) is done here without moving anything until the end. */
+starneig_error_t starneig_amd_schur_sharded_device(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, int rank, int world,
+    double *real, double *imag, struct starneig_schur_conf *conf, void *stream, double *stats);
+
 /* Eigenvalue reordering on a device-resident Schur form (replaces reorder/core.c + cpu.c /
  * cuda.cu:126-761 + the GEMM updates of common/cpu.c:54-162): dS <- U^T dS U, dQ <- dQ U (dQ may
  * be NULL).  selected is a HOST array (in: marks of the selected eigenvalues, out: final positions

@@ -770,8 +770,27 @@ SN_API starneig_error_t starneig_amd_schur_device(
     return rc;
 }
 
+static starneig_error_t schur_replica(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, int rank, int world, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats);
+
 SN_API starneig_error_t starneig_amd_schur_rows_device(
     int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats)
+{
+    return schur_replica(n, dH, ldH, dQrows, ldQ, q_rows, 0, 1, real, imag, conf, stream, stats);
+}
+
+SN_API starneig_error_t starneig_amd_schur_sharded_device(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, int rank, int world, double *real, double *imag,
+    struct starneig_schur_conf *conf, void *stream, double *stats)
+{
+    if (world < 1 || rank < 0 || rank >= world) return -7;
+    return schur_replica(n, dH, ldH, dQrows, ldQ, q_rows, rank, world, real, imag, conf, stream, stats);
+}
+
+static starneig_error_t schur_replica(
+    int n, double *dH, int ldH, double *dQrows, int ldQ, int q_rows, int rank, int world, double *real, double *imag,
     struct starneig_schur_conf *conf, void *stream, double *stats)
 {
     if (n < 1)                 return -1;
@@ -788,6 +807,7 @@ SN_API starneig_error_t starneig_amd_schur_rows_device(
     sn::SchurStats st;
     hipStream_t s = (hipStream_t)stream;
     if (real == NULL || imag == NULL) real = imag = nullptr;
+    prm.shard_rank = rank; prm.shard_world = world;
     rc = sn::schur_device(s, n, dH, ldH, dQrows, ldQ, real, imag, prm, &st, q_rows);
     SN_HIP_CHECK(hipStreamSynchronize(s));
     if (stats) {

@@ -110,6 +110,9 @@ struct SchurParams {            // resolved from starneig_schur_conf (negative =
     double threshold_b = -1.0;  // pencils: deflation threshold of B (right_threshold)
     double threshold_inf = -1.0;// pencils: infinite-eigenvalue threshold (inf_threshold)
     int host_threads = 1;       // starneig_node_init's `cores`: >= 6 gives the host window kernel its helper team (schur_host_team.h)
+    // several GPUs reduce replicas of H (q_rows < n): rank r of `shard_world` alone keeps the 128-column
+    // tiles T of the deflated part with T % shard_world == r up to date; the caller assembles H from them
+    int shard_rank = 0, shard_world = 1;
 };
 struct SchurStats {
     int sweeps = 0, aeds = 0, small_solves = 0, chase_launches = 0;

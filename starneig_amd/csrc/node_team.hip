@@ -259,8 +259,9 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
     return failures.load() == 0 ? 0 : 1;
 }
 
-// Schur leg: every rank reduces a replica of H and accumulates its row block of Q;
-// rank 0 brings H and the eigenvalues back, every rank its rows of Q.  The replicas must agree bit for
+// Schur leg: every rank reduces a replica of H, accumulates its row block of Q and keeps its share of
+// the deflated column tiles of H up to date; every rank brings its rows of Q and its column
+// tiles of H back, the eigenvalues come from the first rank.  The replicas must agree bit for
 // bit: a checksum of the eigenvalues and of diag(S) is compared before anything is written back.
 int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real, double *imag,
     SchurParams const &params, int cores)
@@ -270,6 +271,7 @@ int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real,
     int const ld = (int)roundup(n, 16);
     int const threads = std::max(1, cores / world);
     int const qchunk = (int)roundup(divceil(n, world), 128);
+    int const active = divceil(n, qchunk);                  // ranks that own rows of Q (and reduce a replica)
     std::vector<int> rcs(world, 0);
     std::vector<std::vector<double>> wr(world), wi(world), chk(world);
     std::vector<double *> dHs(world, nullptr), dQs(world, nullptr);
@@ -286,6 +288,7 @@ int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real,
         upload_host_matrix(dQ + r0, ld, Q + r0, ldQ, rows, n, threads);
         SchurParams prm = params;
         prm.host_threads = threads;
+        prm.shard_rank = rank; prm.shard_world = active;    // deflated column tiles of H: one owner each
         wr[rank].assign(n, 0.0); wi[rank].assign(n, 0.0);
         rcs[rank] = schur_device(s, n, dH, ld, dQ + r0, ld, wr[rank].data(), wi[rank].data(), prm, nullptr, rows);
         SN_HIP_CHECK(hipStreamSynchronize(s));
@@ -312,7 +315,11 @@ int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real,
         int const r0 = std::min(n, rank * qchunk), r1 = std::min(n, (rank + 1) * qchunk), rows = r1 - r0;
         if (same) {
             download_host_matrix(Q + r0, ldQ, dQs[rank] + r0, ld, rows, n, threads);
-            if (rank == first) download_host_matrix(H, ldH, dHs[rank], ld, n, n, threads);
+            // column tile T of the Schur form comes from its owner (schur_update_pair_sharded_kernel)
+            for (int T = rank; T * 128 < n; T += active) {
+                int const c0 = T * 128, cols = std::min(128, n - c0);
+                download_host_matrix(H + (size_t)c0 * ldH, ldH, dHs[rank] + (size_t)c0 * ld, ld, n, cols, threads);
+            }
         }
         SN_HIP_CHECK(hipFree(dHs[rank])); SN_HIP_CHECK(hipFree(dQs[rank]));
     });

@@ -334,6 +334,35 @@ void schur_update_pair_kernel(SweepStep const step, double *__restrict__ H, int 
     else schur_update_body<1>(step, H, ldH, nullptr, 0, n, U, r0, r1, blockIdx.x, blockIdx.y);
 }
 
+// The same launch when `world` GPUs reduce replicas of H (the sharded Schur leg).  The columns right of
+// ihi belong to the deflated part: no later window reads or mixes them, they only ever receive further
+// left updates, and each of their entries depends on its own column alone.  So a 128-column tile of
+// them (global tile index T = column / 128, T >= ceil(ihi / 128)) is kept up to date by ONE rank,
+// T % world, and the others skip it -- no exchange during the reduction; the caller assembles H from
+// the owners' tiles at the end (tile T from rank T % world; ihi only shrinks, so a tile that became
+// owner-only stays so).  Columns between the window and the first whole deflated tile stay replicated.
+// blockIdx.x < rep_tiles: the replicated strip; beyond: the rank's own tiles, `world` apart.
+__global__ __launch_bounds__(256, 2)
+void schur_update_pair_sharded_kernel(SweepStep const step, double *__restrict__ H, int ldH, int n,
+    double const *__restrict__ U, int c0, int c1, int r0, int r1, int rep_tiles, int rank, int world)
+{
+    if (blockIdx.z != 0) {
+        schur_update_body<1>(step, H, ldH, nullptr, 0, n, U, r0, r1, blockIdx.x, blockIdx.y);
+        return;
+    }
+    int const first_own = (step.ihi + 127) / 128;                  // first whole tile of deflated columns
+    int const bx = blockIdx.x;
+    if (bx < rep_tiles) {
+        schur_update_body<0>(step, H, ldH, nullptr, 0, n, U, c0, min(c1, first_own * 128), bx, blockIdx.y);
+        return;
+    }
+    int T = first_own + (rank - first_own % world + world) % world + (bx - rep_tiles) * world;
+    int const t0 = max(c0, T * 128), t1 = min(c1, T * 128 + 128);
+    if (t0 >= t1) return;
+    // the window's own columns and its near strip never reach here: T * 128 >= ihi >= lo + w
+    schur_update_body<0>(step, H, ldH, nullptr, 0, n, U, t0, t1, 0, blockIdx.y);
+}
+
 // sub[i] = H(i+1,i) for i in [lo,hi-1); entries below the threshold are set to exactly zero
 // in H as well (the small-sub-diagonal deflation of schur/core.c:1834-1856 / vigilant
 // deflation with the norm-stable criterion).  thres <= 0 selects the LAPACK criterion.
@@ -472,6 +501,8 @@ struct SchurWorkspace {
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_R));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_pair_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_P));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_pair_sharded_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_P));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<2>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, UPDATE_LDS_BYTES_L));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_update_kernel<0>,
@@ -539,6 +570,9 @@ struct Driver {
     // rows of Q this process updates (Q points at the first of them): all n, or the row block of
     // a rank when several GPUs reduce replicas of H and share the accumulation of Q
     int nq = 0;
+    // ... and the rank / number of those GPUs: the deflated columns of H are kept up to date tile by tile
+    // by their owners only (schur_update_pair_sharded_kernel)
+    int shard_rank = 0, shard_world = 1;
 
     // the critical stream waits until the lazy H updates issued so far are done
     void wait_lazy_h()
@@ -864,7 +898,16 @@ struct Driver {
             int const ntasks = it.step.ntasks;
             double *Ubuf = ws.dU + (size_t)it.ev * ws.max_chains * WS_MAX * WS_MAX;
             int const lazy_cols = n - col_split, lazy_rows = it.row_split;
-            if (lazy_cols > 0 || lazy_rows > 0)
+            if (shard_world > 1 && lazy_cols > 0) {
+                // deflated column tiles have one owner each (schur_update_pair_sharded_kernel)
+                int const first_own = divceil(it.step.ihi, 128);
+                int const rep_tiles = std::max(0, divceil(first_own * 128 - col_split, 128));
+                int const own_tiles = std::max(0, divceil(divceil(n, 128) - first_own, shard_world));
+                hipLaunchKernelGGL(schur_update_pair_sharded_kernel,
+                    dim3(std::max(rep_tiles + own_tiles, divceil(std::max(lazy_rows, 1), 128)), ntasks, lazy_rows > 0 ? 2 : 1),
+                    dim3(256), UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows,
+                    rep_tiles, shard_rank, shard_world);
+            } else if (lazy_cols > 0 || lazy_rows > 0)
                 hipLaunchKernelGGL(schur_update_pair_kernel,
                     dim3(divceil(std::max(lazy_cols, lazy_rows), 128), ntasks, lazy_rows > 0 ? 2 : 1), dim3(256),
                     UPDATE_LDS_BYTES_P, ws.hs, it.step, H, ldH, n, Ubuf, col_split, n, 0, lazy_rows);
@@ -1089,10 +1132,11 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
                                                                  : (prm.host_threads >= 6 ? 5 : 0)) : 0;
     // The balance moves with n (the sweeps get longer, the window kernel does not): 0.21 s at 192 / 128
     // against 0.31 s at 256 / 160 for n = 4000, 0.46 s against 0.58 s for n = 8000.
-    // (a replica that carries a row block of Q -- the sharded Schur leg -- must choose the same window
-    // as its peers whatever cores each of them was granted: there the cap does not depend on the helpers)
-    bool const replica = q_rows >= 0 && q_rows < n;
-    int const nw_cap = std::min((helpers >= 2 && !replica) ? 288 : 192, (136 + (int)(0.006 * n) + 8) / 16 * 16);
+    // (a replica that carries a row block of Q -- the sharded Schur leg -- must choose the same window as
+    // its peers: the choice depends on the `cores` the caller states, never on how many helper threads
+    // are actually running, and the callers give every rank the same `cores` -- node_team.hip by
+    // construction, distributed.py checks it; the helper team itself is bit-identical to the serial kernel)
+    int const nw_cap = std::min(helpers >= 2 ? 288 : 192, (136 + (int)(0.006 * n) + 8) / 16 * 16);
     nw_default = std::min(nw_default, nw_cap);
     ns_default = std::min(ns_default, nw_cap * 5 / 8);
     // AED windows above the hard limit (process_args.c:372-398, default 300) are reduced by the
@@ -1168,6 +1212,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     std::vector<double> stale_r, stale_i;
     d.ts = s;
     d.nq = (q_rows >= 0) ? q_rows : n;
+    if (level == 0 && prm.shard_world > 1) { d.shard_rank = prm.shard_rank; d.shard_world = prm.shard_world; }
     d.spw_cap = prm.shifts_per_window;
     // (Round 2 switched the multiplicity off on slowly converging inputs -- fewer than 5 AEDs per sweep
     // over four sweeps -- because the extra chain passes cost accuracy there: all-ones Hessenberg,

@@ -168,11 +168,37 @@ def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
     return rc, stats
 
 
+def owned_h_columns(n, world, device=None):
+    """Columns of the Schur form each rank is the owner of after the sharded reduction: the
+    128-column tiles T with T % world == rank (starneig_amd_schur_sharded_device)."""
+    import torch
+    col = torch.arange(n, device=device)
+    return [col[(col // 128) % world == k] for k in range(world)]
+
+
+def assemble_h_tiles(tH, n, group=None):
+    """Every rank's tH (tH[c] = column c of H) gets the columns of the other ranks' tiles from
+    their owners: one all-gather of the packed tiles, each byte travels once."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    cols = owned_h_columns(n, world, tH.device)
+    per = max(len(c) for c in cols)
+    send = torch.zeros((per, tH.shape[1]), dtype=tH.dtype, device=tH.device)
+    send[:len(cols[rank])] = tH[cols[rank]]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    for k in range(world):
+        if k != rank and len(cols[k]):
+            tH[cols[k]] = recv[k][:len(cols[k])]
+
+
 def schur_sharded(tH, tQ, n=None, conf=None, group=None):
     """Schur reduction of the Hessenberg matrix every rank holds (identically) in tH: each rank
     reduces its replica of H -- the reduction is deterministic, the replicas stay bit-identical,
     no communication -- but accumulates only its row block of Q (half of the update flops of
-    the leg); Q is assembled at the end by one all-gather of the row blocks.
+    the leg) and updates only its own 128-column tiles of the deflated part of H; Q and H are assembled
+    at the end by one all-gather each.
     Returns (rc, real, imag, stats)."""
     import numpy as np
     import torch
@@ -181,10 +207,20 @@ def schur_sharded(tH, tQ, n=None, conf=None, group=None):
     n = tH.shape[0] if n is None else n
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     r0, r1 = owned_q_rows(n, world, rank)
+    if world > 1:
+        # the size of the AED window follows the `cores` of starneig_node_init: replicas only stay
+        # bit-identical if every rank was initialised with the same value
+        cores = torch.tensor([float(L.starneig_node_get_cores())], dtype=torch.float64, device=tH.device)
+        lo, hi = cores.clone(), cores.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if lo.item() != hi.item():
+            raise RuntimeError("starneig_amd: the ranks of a sharded Schur reduction must pass the same "
+                               f"`cores` to starneig_node_init (got {int(lo.item())} .. {int(hi.item())})")
     real, imag = np.zeros(n), np.zeros(n)
     st = (C.c_double * 8)()
-    rc = L.starneig_amd_schur_rows_device(
-        n, tH.data_ptr(), tH.shape[1], tQ.data_ptr() + 8 * r0, tQ.shape[1], r1 - r0,
+    rc = L.starneig_amd_schur_sharded_device(
+        n, tH.data_ptr(), tH.shape[1], tQ.data_ptr() + 8 * r0, tQ.shape[1], r1 - r0, rank, world,
         real.ctypes.data, imag.ctypes.data, C.byref(conf) if conf is not None else None,
         torch.cuda.current_stream().cuda_stream, st)
     # tQ has shape (columns, ld): dimension 1 runs over the rows of the column-major matrix
@@ -215,6 +251,9 @@ def schur_sharded(tH, tQ, n=None, conf=None, group=None):
             if k != rank and b > a:
                 tQ[:n, a:b] = recv[k][:, :b - a]
         del send, recv
+        # the deflated column tiles of H were kept up to date by their owners only (tile T by rank
+        # T % world, include/starneig_amd.h): one all-gather of the packed tiles assembles the Schur form
+        assemble_h_tiles(tH, n, group)
     stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
              "aed_host_s": st[6], "gpu_wait_s": st[7], "q_rows": (r0, r1)}

@@ -103,6 +103,9 @@ SIGNATURES = {
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_schur_rows_device": (
         C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.POINTER(SchurConf), _vp, _dp]),
+    "starneig_amd_schur_sharded_device": (
+        C.c_int, [C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                  C.POINTER(SchurConf), _vp, _dp]),
     "starneig_amd_hessenberg_device": (
         C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _dp]),
     "starneig_amd_hessenberg_panel_ld": (C.c_int, [C.c_int, C.c_int]),
@@ -374,6 +377,23 @@ def schur_device(tH, tQ, n=None, conf=None, eigenvalues=True):
     rc = load().starneig_amd_schur_device(
         n, _dev_ptr(tH), tH.shape[1], _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0,
         None if real is None else real.ctypes.data, None if imag is None else imag.ctypes.data,
+        C.byref(conf) if conf is not None else None, _stream_ptr(), st)
+    stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
+             "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],
+             "aed_host_s": st[6], "gpu_wait_s": st[7]}
+    return rc, real, imag, stats
+
+
+def schur_sharded_device(tH, tQrows, q_rows, rank, world, n=None, conf=None):
+    """One rank's share of the sharded Schur leg (starneig_amd_schur_sharded_device): a replica of H,
+    q_rows rows of Q starting at tQrows (a device pointer or a tensor), the deflated column tiles T of
+    H with T % world == rank.  Returns (rc, real, imag, stats)."""
+    n = tH.shape[0] if n is None else n
+    real, imag = np.zeros(n), np.zeros(n)
+    st = (C.c_double * 8)()
+    qptr, ldq = (tQrows.data_ptr(), tQrows.shape[1]) if hasattr(tQrows, "data_ptr") else tQrows
+    rc = load().starneig_amd_schur_sharded_device(
+        n, _dev_ptr(tH), tH.shape[1], qptr, ldq, q_rows, rank, world, real.ctypes.data, imag.ctypes.data,
         C.byref(conf) if conf is not None else None, _stream_ptr(), st)
     stats = {"total_ms": st[0], "sweeps": int(st[1]), "aeds": int(st[2]),
              "small_solves": int(st[3]), "chase_launches": int(st[4]), "gemm_flops": st[5],

@@ -6,7 +6,7 @@ import subprocess
 import sys
 import textwrap
 
-from starneig_amd.distributed import owned_column_blocks, owned_q_rows
+from starneig_amd.distributed import owned_column_blocks, owned_h_columns, owned_q_rows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,6 +22,11 @@ def test_ownership_partitions_the_matrix():
             lo, hi = owned_q_rows(n, world, r)
             rows += list(range(lo, hi))
         assert sorted(rows) == list(range(n))
+        # Schur leg: the 128-column tiles of the deflated part of H, tile T with rank T mod world
+        hcols = owned_h_columns(n, world)
+        assert sorted(int(c) for cs in hcols for c in cs) == list(range(n))
+        for r, cs in enumerate(hcols):
+            assert all((int(c) // 128) % world == r for c in cs)
     # load balance of the trailing matrix at n=20000 on 8 GPUs: every rank owns 8 +- 1 blocks
     counts = [len(owned_column_blocks(20000, 312, 8, r)) for r in range(8)]
     assert max(counts) - min(counts) <= 1
@@ -46,6 +51,16 @@ WORKER = textwrap.dedent('''
     ep = torch.full((6,), float(rank + 5), dtype=torch.float64); ep[1:4] = 6.0
     assert torch.equal(p, ep), (rank, p)
     assert coll.calls == {"allreduce": 1, "broadcast": 1, "bytes": 64}
+    # assembly of the Schur form from the owners' column tiles (schur_sharded): each rank holds
+    # garbage in the tiles it does not own, the right values in its own
+    from starneig_amd.distributed import assemble_h_tiles, owned_h_columns
+    n, ld = 700, 704
+    full = torch.arange(n * ld, dtype=torch.float64).reshape(n, ld)
+    mine = torch.full((n, ld), -1.0 - rank, dtype=torch.float64)
+    own = owned_h_columns(n, 2)[rank]
+    mine[own] = full[own]
+    assemble_h_tiles(mine, n)
+    assert torch.equal(mine, full), rank
     print("PLUMBING-OK", rank, flush=True)
     dist.destroy_process_group()
 ''') % ROOT

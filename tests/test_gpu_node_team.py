@@ -57,6 +57,25 @@ def test_c_interface_on_several_gpus(team, gpus, n):
     assert O.match_eigenvalues(real + 1j * imag, wro + 1j * wio) < 1e4
 
 
+@pytest.mark.parametrize("gpus,n", [(2, 1500), (3, 3000)])
+def test_team_schur_equals_the_single_gpu_reduction_bit_for_bit(team, node, gpus, n):
+    """every rank reduces a replica of H but updates only its rows of Q and its own column tiles of the
+    deflated part of H (schur_update_pair_sharded_kernel): what comes back, assembled from the owners,
+    is the single-GPU result bit for bit (n = 3000 has look-ahead sweeps: phase A and phase B)"""
+    H0 = O.random_fullpos(n)
+    Q0 = O.identity(n)
+    assert node.SEP_SM_Hessenberg(n, H0, H0.shape[0], Q0, Q0.shape[0]) == 0
+    H1 = H0.copy(order="F"); Q1 = Q0.copy(order="F"); r1 = np.zeros(n); i1 = np.zeros(n)
+    assert node.SEP_SM_Schur(n, H1, H1.shape[0], Q1, Q1.shape[0], r1, i1) == 0
+    S = team(gpus)
+    H2 = H0.copy(order="F"); Q2 = Q0.copy(order="F"); r2 = np.zeros(n); i2 = np.zeros(n)
+    assert S.SEP_SM_Schur(n, H2, H2.shape[0], Q2, Q2.shape[0], r2, i2) == 0
+    assert np.array_equal(r1, r2) and np.array_equal(i1, i2)
+    assert np.array_equal(Q1[:n], Q2[:n])
+    bad = np.argwhere(H1[:n] != H2[:n])
+    assert bad.size == 0, (len(bad), bad[:5], "columns / 128:", np.unique(bad[:, 1] // 128)[:10])
+
+
 def test_gpus_request_is_clamped_and_partial_ranges_stay_on_one_device(team):
     S = team(2)
     L = S.lib.load()

@@ -330,3 +330,42 @@ def test_blocked_aed_for_windows_above_the_hard_limit(node, n, nw, ns):
     assert O.match_eigenvalues(real2 + 1j * imag2, real0 + 1j * imag0) < 1e4
     print(f"n={n} window {nw}: blocked {st['total_ms']:.0f} ms ({st['aeds']} AEDs, {st['sweeps']} sweeps), "
           f"host kernel {st2['total_ms']:.0f} ms ({st2['aeds']} AEDs), default {st0['total_ms']:.0f} ms ({st0['aeds']} AEDs)")
+
+
+@pytest.mark.parametrize("world,n", [(2, 3500), (3, 5000)])
+def test_owner_only_tiles_of_the_deflated_columns(node, world, n):
+    """Sharded Schur leg (include/starneig_amd.h, starneig_amd_schur_sharded_device): rank r of `world`
+    keeps only the 128-column tiles T of the deflated part with T % world == r up to date.  Each rank's
+    replica must (a) agree with the single-GPU reduction in its own tiles, on and below the diagonal
+    blocks and in the eigenvalues, (b) really skip work -- differ from it in tiles of the others --
+    and (c) the tiles taken from their owners give the single-GPU Schur form bit for bit."""
+    import torch
+    tA0 = node.device_matrix(n)
+    assert node.lcg_fill_device(tA0, n, n, seed=2019, mode=0) == 0
+    tH0 = tA0.clone(); tQ0 = node.device_matrix(n)
+    node.set_matrix_device(tQ0, n, n, 0.0, 1.0)
+    assert node.hessenberg_device(tH0, tQ0, n=n) == 0
+    tH1, tQ1 = tH0.clone(), tQ0.clone()
+    rc, real1, imag1, _ = node.schur_device(tH1, tQ1, n=n)
+    assert rc == 0
+    tile = torch.arange(n, device=tH1.device) // 128
+    assembled = torch.empty_like(tH1)
+    for rank in range(world):
+        tH, tQ = tH0.clone(), tQ0.clone()
+        rc, real, imag, _ = node.schur_sharded_device(tH, tQ, n, rank, world, n=n)
+        torch.cuda.synchronize()
+        assert rc == 0
+        assert np.array_equal(real, real1) and np.array_equal(imag, imag1)
+        assert torch.equal(tQ, tQ1)                                   # all rows of Q were this rank's here
+        own = (tile % world) == rank                                  # tH[c] is column c of H
+        assert torch.equal(tH[own], tH1[own])
+        differs = (tH[~own] != tH1[~own])
+        assert differs.any(), "no tile was skipped: the reduction was not sharded"
+        # tile 0 is never owner-only; what differs lies above the tile's first row: a tile becomes
+        # owner-only when the active block ends at or above its first column
+        assert torch.equal(tH[tile == 0], tH1[tile == 0])
+        cols = torch.nonzero(~own).flatten()[torch.nonzero(differs)[:, 0]]
+        rows = torch.nonzero(differs)[:, 1]
+        assert bool((rows < cols // 128 * 128).all())
+        assembled[own] = tH[own]
+    assert torch.equal(assembled, tH1)
