@@ -13,7 +13,8 @@ At N > 1 the N GPUs reduce ONE matrix together (strong scaling): the Hessenberg 
 sharded by block column (per-column all-reduce of the partial y = A v, panel broadcast,
 starneig_amd/distributed.py); in the Schur leg every rank reduces its replica of H (the
 latency-bound chain of window steps and host AEDs does not shard) but accumulates only its
-row block of Q -- 45 % of the update flops -- and Q is assembled by one all-reduce.
+row block of Q -- 45 % of the update flops -- and keeps only its own 128-column tiles of the
+deflated part of H up to date; Q and H are assembled by one all-gather each.
 """
 import argparse
 import json
@@ -574,8 +575,9 @@ def main():
                 "n": n, "panel_width": S.default_panel_width(n),
                 "parallelism": "single GPU" if not sharded else
                                f"Hessenberg sharded by block column over {world} GPU(s) (RCCL: per-column "
-                               f"all-reduce of y, panel broadcast); Schur: H replicated, accumulation of Q "
-                               f"sharded by row block (one all-reduce at the end)",
+                               f"all-reduce of y, panel broadcast); Schur: band of H replicated, accumulation of Q "
+                               f"sharded by row block, left updates of the deflated columns of H by "
+                               f"128-column tile (one all-gather each at the end)",
                 "collectives": stats[-1].get("collectives"),
                 "residual_u": chk["residual_u"], "orthogonality_u": chk["orthogonality_u"],
                 "below_subdiagonal_nonzeros": chk["below_subdiagonal"],
