@@ -262,8 +262,9 @@ def cpu_baseline(n_lapack, n_port):
     if n_port > 0:
         import oracle as O
         import starneig_amd as S
-        nthr = min(cores, 32)                   # (plain-loop kernels on 128-row windows: more threads than this only add overhead)
-        os.environ.setdefault("OMP_NUM_THREADS", str(nthr))
+        # (plain-loop kernels on 128-row windows: more threads than this only add overhead; set through the
+        # OpenMP runtime, not the environment -- the runtime read that when torch loaded it)
+        nthr = O.set_threads(min(cores, 32))
         hooks = S.lib.load_test_hooks()         # host-only window kernels of the product (csrc/schur_host.hip)
         A0 = O.random_fullpos(n_port)
         A = A0.copy(order="F")
@@ -277,9 +278,9 @@ def cpu_baseline(n_lapack, n_port):
         res = O.residual_u(Q, A, A0)
         assert res < 500.0, f"CPU port residual {res} u"
         out.update({"value": (hess_flops(n_port) + schur_flops(n_port)) / (t2 - t0) / 1e9,
-                    "cores": int(os.environ["OMP_NUM_THREADS"]),
+                    "cores": nthr,
                     "sample": f"CPU restatement of the reference algorithm on the LCG matrix at n={n_port}, "
-                              f"{os.environ['OMP_NUM_THREADS']} OpenMP threads: Hessenberg {t1 - t0:.1f} s "
+                              f"{nthr} OpenMP threads: Hessenberg {t1 - t0:.1f} s "
                               f"(oracle/hessenberg_oracle.c: the reference's panel / column / update order), Schur "
                               f"{t2 - t1:.1f} s (oracle/msqr_port.c: multishift QR with AED, {st['sweeps']} sweeps, "
                               f"{st['aeds']} AED windows -- chains of packed bulges through diagonal windows, "
@@ -437,7 +438,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=4000,
                     help="size of the LAPACK CPU-baseline sample (0 = skip; n=4000 is ~30 s on the GPU box's host, "
                          "n=8000 ~4 min)")
-    ap.add_argument("--cpu-port-n", type=int, default=2500,
+    ap.add_argument("--cpu-port-n", type=int, default=3000,
                     help="size of the oracle-port CPU sample (0 = skip)")
     ap.add_argument("--host-api", type=int, default=1,
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")

@@ -255,3 +255,15 @@ int oracle_msqr_port(int n, double *H, int ldh, double *Q, int ldq, int nw, int 
     if (stats) { stats[0] = sweeps; stats[1] = aeds; stats[2] = flops; stats[3] = t_aed; }
     return rc;
 }
+
+// Thread count of the OpenMP regions of the oracle (bench.py's cpu_baseline: the environment variable is read
+// when the OpenMP runtime starts, which in a process that imported torch was long ago).  Returns the count in force.
+int oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}

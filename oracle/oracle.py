@@ -73,6 +73,8 @@ def lib():
         L.oracle_msqr_port.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, dp]
         L.oracle_msqr_port.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_threads.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -386,6 +388,11 @@ def eigenvalues_check(extracted, returned, warn=1e3, fail=1e4):
 
 
 # ---- CPU port of the multishift QR / AED Schur leg (oracle/msqr_port.c; bench.py's cpu_baseline) ----
+
+def set_threads(n):
+    """OpenMP threads of the oracle's parallel regions from here on (n <= 0: leave as is); returns the count in force."""
+    return int(lib().oracle_set_threads(int(n)))
+
 
 def msqr_port(H, Q, aed_fn, small_fn, nw=None, ns=None, W=128, small_limit=128):
     """In place: the upper Hessenberg (ld, n) array H -> real Schur form, Q <- Q U, by the multi-threaded

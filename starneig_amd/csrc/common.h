@@ -43,6 +43,7 @@ void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int l
     double *X, int ldx);
 
 // ---- small helpers (util.hip) -----------------------------------------------
+void make_stream(hipStream_t *s, bool critical, int prio, int free_cus = 0);
 void copy_matrix(hipStream_t s, int m, int n, double const *A, int lda,
     double *B, int ldb);
 void set_matrix(hipStream_t s, int m, int n, double value, double diag,

@@ -771,9 +771,9 @@ struct HtWorkspace {
             for (auto &e : ev) SN_HIP_CHECK(hipEventCreate(&e));
             int lo = 0, hi = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // lo = least urgent
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, hi));
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&qstream, hipStreamNonBlocking, lo));
+            make_stream(&main, true, hi);
+            make_stream(&side, false, lo);
+            make_stream(&qstream, false, lo);
             for (auto &e : e_q) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_cdone, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_scan, hipEventDisableTiming));

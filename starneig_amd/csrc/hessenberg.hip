@@ -534,6 +534,18 @@ struct HessWorkspace {
         if (tile_cnt) { SN_HIP_CHECK(hipFree(tile_cnt)); tile_cnt = nullptr; }
         n = nbmax = 0; ysplits = 0;
     }
+    // streams and events go when the owning thread lets the workspace go (node finalize, the end of a team
+    // thread): a stream holds a reference on a hardware queue -- or, created with a CU mask, the queue itself
+    void destroy_streams() {
+        auto kill = [](hipEvent_t &e) { if (e) { SN_HIP_CHECK(hipEventDestroy(e)); e = nullptr; } };
+        if (main) { SN_HIP_CHECK(hipStreamDestroy(main)); main = nullptr; }
+        if (side) { SN_HIP_CHECK(hipStreamDestroy(side)); side = nullptr; }
+        kill(entry); kill(ev0); kill(ev1);
+        for (int k = 0; k < 2; k++) { kill(panel_done[k]); kill(side_done[k]); }
+        for (hipEvent_t &e : gemm_ev) kill(e);
+        for (hipEvent_t &e : sample_ev) kill(e);
+        gemm_ev.clear(); sample_ev.clear();
+    }
     void ensure(int n_, int nb_) {
         int const need_splits = std::max(MAX_SPLIT, divceil(n_, std::max(8, nb_)) + 1);
         if (n_ <= n && nb_ <= nbmax && need_splits <= ysplits) return;
@@ -560,7 +572,7 @@ struct HessWorkspace {
             int lo = 0, hi = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest
             // the latency-critical panel chain outranks the bulk GEMM updates
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&main, hipStreamNonBlocking, hi));
+            make_stream(&main, true, hi);
             if (tuning().hess_side_cus > 0) {
                 // experiment: the delayed updates confined to the first `hess_side_cus` CUs
                 hipDeviceProp_t prop; int dev = 0;
@@ -570,7 +582,7 @@ struct HessWorkspace {
                 for (int i = 0; i < std::min(ncu, tuning().hess_side_cus); i++) mask[i / 32] |= 1u << (i % 32);
                 SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&side, words, mask.data()));
             } else
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
+            make_stream(&side, false, lo);
             SN_HIP_CHECK(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
             for (int k = 0; k < 2; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&panel_done[k], hipEventDisableTiming));
@@ -586,7 +598,7 @@ struct HessWorkspace {
 // multi-GPU path (node_team.hip) on one persistent thread per device
 static thread_local HessWorkspace g_ws;
 
-void hessenberg_release_workspace() { g_ws.release(); }
+void hessenberg_release_workspace() { g_ws.release(); g_ws.destroy_streams(); }
 
 int hessenberg_panel_ld(int n, int) { return (int)roundup((size_t)n + GEMV_ROWS + 16, 128); }
 

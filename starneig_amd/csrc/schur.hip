@@ -248,6 +248,7 @@ __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
+    __builtin_amdgcn_s_setprio(3);      // the latency-bound chain outranks the update kernels in instruction issue
     schur_chase_body<0>(step, H, ldH, Uout, sr, si);
 }
 #ifdef SN_TEST_HOOKS
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256, 2)
 void schur_update_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Q, int ldQ, int n, double const *__restrict__ U, int r0, int r1)
 {
+    if (MODE != 3) __builtin_amdgcn_s_setprio(2);      // timely updates (the lazy ones keep priority 0)
     schur_update_body<MODE, RBM>(step, H, ldH, Q, ldQ, n, U, r0, r1, blockIdx.x, blockIdx.y);
 }
 
@@ -433,6 +435,21 @@ struct SchurWorkspace {
         for (auto p : hptrs) if (*p) { SN_HIP_CHECK(hipHostFree(*p)); *p = nullptr; }
         n = nwmax = max_chains = 0;
     }
+    // streams and events go when the owning thread lets the workspace go (node finalize, the end of a team
+    // thread): a stream holds a reference on a hardware queue -- or, created with a CU mask, the queue itself
+    void destroy_streams() {
+        if (!attr_set) return;
+        auto kill = [](hipEvent_t &e) { if (e) { SN_HIP_CHECK(hipEventDestroy(e)); e = nullptr; } };
+        for (hipStream_t *st : {&far, &qs, &hs, &aed}) if (*st) { SN_HIP_CHECK(hipStreamDestroy(*st)); *st = nullptr; }
+        for (int k = 0; k < EV_RING; k++) { kill(near_done[k]); kill(far_done[k]); }
+        for (int k = 0; k < FLUSH_RING; k++) { kill(q_done[k]); kill(h_done[k]); }
+        for (int k = 0; k < Z_RING; k++) { kill(z_ready[k]); kill(z_done[k]); kill(zh_done[k]); }
+        kill(lazy_mark); kill(aed_mark);
+        // the rings restart with the fresh events
+        flush_total = 0; issued_total = 0; z_total = 0; shift_uploads = 0;
+        std::fill(slot_flush.begin(), slot_flush.end(), -1L);
+        attr_set = false;
+    }
     void ensure(int n_, int nw_, int chains_) {
         if (n_ <= n && nw_ <= nwmax && chains_ <= max_chains) return;
         release();
@@ -459,7 +476,7 @@ struct SchurWorkspace {
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&far, hipStreamNonBlocking, hi_prio));
+            make_stream(&far, true, hi_prio);
             int const keep_free = tuning().schur_cumask;
             if (keep_free > 0) {
                 // experiment: the lazy update streams may not use the first `keep_free` CUs
@@ -471,12 +488,12 @@ struct SchurWorkspace {
                 SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&qs, words, mask.data()));
                 SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&hs, words, mask.data()));
             } else {
-                SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
+                make_stream(&qs, false, lo_prio, tuning().stream_lazy_free);
                 // the lazy H stream -- the one the critical stream waits for at the start of every sweep --
                 // one level above the lazy Q stream, which nobody waits for before the end (measured at
                 // n = 20000: 2.60 s against 2.70 s with both at the lowest priority)
                 int const hs_prio = tuning().schur_hs_prio ? std::max(hi_prio, lo_prio - 1) : lo_prio;
-                SN_HIP_CHECK(hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, hs_prio));
+                make_stream(&hs, false, hs_prio, tuning().stream_lazy_free);
             }
             for (int k = 0; k < EV_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&near_done[k], hipEventDisableTiming));
@@ -488,7 +505,7 @@ struct SchurWorkspace {
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
             // (high priority: a hardware-queue pool of its own, see schur_device)
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&aed, hipStreamNonBlocking, hi_prio));
+            make_stream(&aed, true, hi_prio);
             SN_HIP_CHECK(hipEventCreateWithFlags(&aed_mark, hipEventDisableTiming));
             for (int k = 0; k < Z_RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&z_ready[k], hipEventDisableTiming));
@@ -538,7 +555,18 @@ struct LargeAedBuffers {
     }
 };
 static thread_local LargeAedBuffers g_large;
-void schur_release_workspace() { g_sws[0].release(); g_sws[1].release(); g_large.release(); }
+// the reduction's own stream per recursion level (schur_device) and the event that orders it behind the caller's
+static thread_local hipStream_t own_[2] = {nullptr, nullptr};
+static thread_local hipEvent_t fence_[2] = {nullptr, nullptr};
+void schur_release_workspace()
+{
+    for (int l = 0; l < 2; l++) {
+        g_sws[l].release(); g_sws[l].destroy_streams();
+        if (own_[l]) { SN_HIP_CHECK(hipStreamDestroy(own_[l])); own_[l] = nullptr; }
+        if (fence_[l]) { SN_HIP_CHECK(hipEventDestroy(fence_[l])); fence_[l] = nullptr; }
+    }
+    g_large.release();
+}
 
 // LAPACK iparmq-style minimum, then the reference's rules (schur/process_args.c:116-162)
 static int lapack_min_shifts(int n)
@@ -1099,8 +1127,6 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 {
     // the whole reduction runs on the library's own stream pair (never on the legacy NULL
     // stream), fenced against the caller's stream at entry and exit
-    static thread_local hipStream_t own_[2] = {nullptr, nullptr};
-    static thread_local hipEvent_t fence_[2] = {nullptr, nullptr};
     hipStream_t &own = own_[level];
     hipEvent_t &fence = fence_[level];
     if (!own) {
@@ -1111,7 +1137,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
         // queue behind lazy updates.
         int lo_prio = 0, hi_prio = 0;
         SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-        SN_HIP_CHECK(hipStreamCreateWithPriority(&own, hipStreamNonBlocking, hi_prio));
+        make_stream(&own, true, hi_prio);
         SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
     }
     hipStream_t s = own;

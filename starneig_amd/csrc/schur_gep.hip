@@ -327,9 +327,9 @@ struct GepWorkspace {
                 hipFuncAttributeMaxDynamicSharedMemorySize, GEP_CHASE_LDS_BYTES));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&far, hipStreamNonBlocking, hi_prio));   // see schur.hip
+            make_stream(&far, true, hi_prio);   // see schur.hip
 
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&qs, hipStreamNonBlocking, lo_prio));
+            make_stream(&qs, false, lo_prio);
             SN_HIP_CHECK(hipEventCreateWithFlags(&lazy_mark, hipEventDisableTiming));
             for (int k = 0; k < FLUSH_RING; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&q_done[k], hipEventDisableTiming));
             for (int k = 0; k < Z_RING; k++) {
@@ -652,7 +652,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     if (!own) {
         int lo_prio = 0, hi_prio = 0;          // highest priority: see schur.hip
         SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-        SN_HIP_CHECK(hipStreamCreateWithPriority(&own, hipStreamNonBlocking, hi_prio));
+        make_stream(&own, true, hi_prio);
         SN_HIP_CHECK(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
     }
     hipStream_t s = own;

@@ -23,6 +23,11 @@ struct Tuning {
     bool aed_profile = false;       // SN_AED_PROFILE
     bool schur_hs_prio = true;      // SN_SCHUR_HS_PRIO=0: lazy H stream at the priority of the lazy Q stream (else one level above)
     int schur_cumask = 0;           // SN_SCHUR_CUMASK: CUs kept free of the lazy update streams (0 = no mask)
+    // streams
+    int stream_mode = 0;            // SN_STREAM_MODE: bit 0 critical streams, bit 1 lazy streams on hardware queues of their own (util.hip make_stream)
+    int stream_lazy_free = 0;       // SN_STREAM_LAZY_FREE: CUs the lazy update streams of the Schur leg may not use (with bit 1 of the mode)
+    char const *stream_space = nullptr; // SN_STREAM_SPACE: digit k = dummy queues created before the k-th stream (experiment)
+    int stream_pad = 0;             // SN_STREAM_PAD: dummy high-priority streams created first (what a host application may have done)
     // GEMM
     bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)
     bool gemm_nosplit = false;      // SN_GEMM_NOSPLIT: whole tiles in the last round of workgroups too

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace sn {
 
@@ -31,6 +32,10 @@ Tuning const &tuning()
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);
         t.schur_hs_prio = geti("SN_SCHUR_HS_PRIO", 1) != 0;
+        t.stream_mode = geti("SN_STREAM_MODE", t.stream_mode);
+        t.stream_pad = geti("SN_STREAM_PAD", t.stream_pad);
+        t.stream_space = getenv("SN_STREAM_SPACE");
+        t.stream_lazy_free = geti("SN_STREAM_LAZY_FREE", t.stream_lazy_free);
         t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
         t.gemm_nosplit = getb("SN_GEMM_NOSPLIT");
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
@@ -40,6 +45,49 @@ Tuning const &tuning()
         return t;
     }();
     return t;
+}
+
+// A stream of the library.  critical: on the latency-bound chain of a reduction (high priority) -- else a
+// bulk / lazy stream (priority `prio`).  The HIP runtime multiplexes the streams of one priority onto four
+// hardware queues, whoever created them; a stream created with a CU mask gets a queue of its own.
+void make_stream(hipStream_t *s, bool critical, int prio, int free_cus)
+{
+    static thread_local bool padded = false;
+    if (!padded) {
+        padded = true;
+        int lo = 0, hi = 0;
+        SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (int k = 0; k < tuning().stream_pad; k++) {
+            hipStream_t d;
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&d, hipStreamNonBlocking, hi));
+        }
+    }
+    // experiment: dummy queues of their own created before the k-th stream of this thread (SN_STREAM_SPACE=abcde...)
+    static thread_local int created = 0;
+    {
+        char const *sp = tuning().stream_space;
+        int const k = created++;
+        if (sp && (int)strlen(sp) > k)
+            for (int q = 0; q < sp[k] - '0'; q++) {
+                hipDeviceProp_t prop; int dev = 0;
+                SN_HIP_CHECK(hipGetDevice(&dev)); SN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                int const ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+                std::vector<uint32_t> mask(words, 0xffffffffu);
+                hipStream_t d;
+                SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&d, words, mask.data()));
+            }
+    }
+    int const mode = tuning().stream_mode;
+    bool const dedicated = critical ? (mode & 1) : (mode & 2);
+    if (dedicated) {
+        hipDeviceProp_t prop; int dev = 0;
+        SN_HIP_CHECK(hipGetDevice(&dev)); SN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        int const ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0u);
+        for (int i = std::max(0, free_cus); i < ncu; i++) mask[i / 32] |= 1u << (i % 32);
+        SN_HIP_CHECK(hipExtStreamCreateWithCUMask(s, words, mask.data()));
+    } else
+        SN_HIP_CHECK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio));
 }
 
 __global__ void copy_matrix_kernel(int m, int n, double const *__restrict__ A, int lda,
