@@ -27,6 +27,7 @@ struct Tuning {
     int stream_mode = 0;            // SN_STREAM_MODE: bit 0 critical streams, bit 1 lazy streams on hardware queues of their own (util.hip make_stream)
     int stream_lazy_free = 0;       // SN_STREAM_LAZY_FREE: CUs the lazy update streams of the Schur leg may not use (with bit 1 of the mode)
     char const *stream_space = nullptr; // SN_STREAM_SPACE: digit k = dummy queues created before the k-th stream (experiment)
+    int stream_pad_prio = 0;        // SN_STREAM_PAD_PRIO: priority level of those dummy streams (0 high, 1 normal, 2 low)
     int stream_pad = 0;             // SN_STREAM_PAD: dummy high-priority streams created first (what a host application may have done)
     // GEMM
     bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)

@@ -35,6 +35,7 @@ Tuning const &tuning()
         t.stream_mode = geti("SN_STREAM_MODE", t.stream_mode);
         t.stream_pad = geti("SN_STREAM_PAD", t.stream_pad);
         t.stream_space = getenv("SN_STREAM_SPACE");
+        t.stream_pad_prio = geti("SN_STREAM_PAD_PRIO", t.stream_pad_prio);
         t.stream_lazy_free = geti("SN_STREAM_LAZY_FREE", t.stream_lazy_free);
         t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
         t.gemm_nosplit = getb("SN_GEMM_NOSPLIT");
@@ -59,7 +60,8 @@ void make_stream(hipStream_t *s, bool critical, int prio, int free_cus)
         SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         for (int k = 0; k < tuning().stream_pad; k++) {
             hipStream_t d;
-            SN_HIP_CHECK(hipStreamCreateWithPriority(&d, hipStreamNonBlocking, hi));
+            int const level = tuning().stream_pad_prio;     // 0 high, 1 normal, 2 low
+            SN_HIP_CHECK(hipStreamCreateWithPriority(&d, hipStreamNonBlocking, level == 0 ? hi : (level == 2 ? lo : (hi + lo) / 2)));
         }
     }
     // experiment: dummy queues of their own created before the k-th stream of this thread (SN_STREAM_SPACE=abcde...)
