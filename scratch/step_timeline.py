@@ -7,10 +7,10 @@ def pick(sub, excl=None):
     r = [(int(x["Start_Timestamp"]), int(x["End_Timestamp"]), x.get("Queue_Id", "?")) for x in rows
          if sub in x["Kernel_Name"] and (excl is None or excl not in x["Kernel_Name"])]
     return sorted(r)
-chase = pick("schur_chase_kernel")
+chase = pick("schur_chase_")
 names = sorted({x["Kernel_Name"].split("(")[0] for x in rows if "schur_update" in x["Kernel_Name"]})
 print("update kernel names:", names)
-near = pick("schur_update_kernel<2")
+near = pick("schur_near_kernel") or pick("schur_update_kernel<2")
 far0 = pick("schur_update_kernel<0")
 far1 = pick("schur_update_kernel<1")
 pair = pick("schur_update_pair")
