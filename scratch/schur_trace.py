@@ -10,7 +10,7 @@ tA = S.device_matrix(n); S.lcg_fill_device(tA, n, n, seed=2019, mode=0)
 tQ = S.device_matrix(n); S.set_matrix_device(tQ, n, n, 0.0, 1.0)
 rc, st = S.hessenberg_device(tA, tQ, n=n, stats=True); torch.cuda.synchronize()
 tH0, tQ0 = tA.clone(), tQ.clone()
-for rep in range(2):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     tA.copy_(tH0); tQ.copy_(tQ0); torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc, re, im, sst = S.schur_device(tA, tQ, n=n)
