@@ -450,15 +450,25 @@ __global__ __launch_bounds__(64) void ht_qpass2_kernel(double *__restrict__ Q, i
 // load in flight at once, one half-wave runs the 512-step recurrence out of LDS, and the block goes
 // back in one sweep of stores.
 constexpr int CL_ROWS = 32, CL_COLS = HGR_MAX + 1;
-constexpr int CL_LDS_BYTES = (CL_COLS * CL_ROWS + 2 * HGR_MAX) * 8;
+constexpr int CL_NPH = 256 / CL_ROWS;                   // column phases of the loads = segments of the recurrence
+constexpr int CL_LDS_BYTES = (CL_COLS * CL_ROWS + 2 * HGR_MAX + 2 * CL_NPH * CL_ROWS) * 8;
+// The recurrence along a row -- rotation i reads the ORIGINAL column i and the carried value y, writes
+// column i+1 and passes y on -- is affine in the carry over any run of rotations (y_out = a y_in + b, the
+// trick of the row pass).  So it does not have to be ONE chain of up to 512 dependent steps on a
+// half-wave while seven others wait: the rotations are cut into CL_NPH segments, every half-wave runs its
+// segment once from a zero carry to get (a, b), the incoming carries follow from at most seven
+// multiply-adds, and every half-wave runs its segment again with the right carry: 2 x 64 + 7 dependent
+// steps instead of 512.  (Each segment's results are those of the serial recurrence from its incoming
+// carry; the carries differ from the serial ones by the rounding of a y + b.)
 __global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict__ M, int ld, int rows,
     int t_hi, int t_lo, double const *__restrict__ Cc, double const *__restrict__ Cs)
 {
     extern __shared__ double lds[];
     double (*tile)[CL_ROWS] = (double (*)[CL_ROWS])lds;             // [column t - (t_lo - 1)][row]
     v2d *cs = (v2d *)(lds + CL_COLS * CL_ROWS);                     // [t - t_lo]
+    v2d (*seg)[CL_ROWS] = (v2d (*)[CL_ROWS])(lds + CL_COLS * CL_ROWS + 2 * HGR_MAX);    // (a, b) of a segment, per row
     int const tid = threadIdx.x, r = tid & (CL_ROWS - 1), sub = tid / CL_ROWS;      // NPH column phases
-    constexpr int NPH = 256 / CL_ROWS, NLD = (CL_COLS + 2 * NPH - 1) / (2 * NPH);   // two batches of NLD loads
+    constexpr int NPH = CL_NPH, NLD = (CL_COLS + 2 * NPH - 1) / (2 * NPH);          // two batches of NLD loads
     int const row = blockIdx.x * CL_ROWS + r;
     int const ncol = t_hi - t_lo + 2;                               // columns t_lo - 1 .. t_hi
     bool const rv = row < rows;
@@ -472,10 +482,31 @@ __global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict_
     }
     for (int i = tid; i < ncol - 1; i += 256) cs[i] = v2d{Cc[t_lo + i], Cs[t_lo + i]};
     __syncthreads();
-    if (tid < CL_ROWS) {
-        double y = tile[ncol - 1][r];
-        int i = ncol - 2;                                           // rotation t = t_lo + i: columns i (t-1) and i+1 (t)
-        for (; i >= 7; i -= 8) {                                    // reads of a batch first: the writes go to other columns
+    // rotation t = t_lo + i acts on columns i (t-1) and i+1 (t); segment `sub` holds i = hi .. lo, right to left
+    int const nrot = ncol - 1, seglen = (nrot + NPH - 1) / NPH;
+    int const hi = nrot - 1 - sub * seglen, lo = max(hi - seglen + 1, 0);
+    {
+        double a = 1.0, b = 0.0;
+        int i = hi;
+        for (; i - 7 >= lo; i -= 8) {                               // reads of a batch first
+            double x[8]; v2d k[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { x[q] = tile[i - q][r]; k[q] = cs[i - q]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { b = k[q].x * x[q] - k[q].y * b; a = -k[q].y * a; }
+        }
+        for (; i >= lo; i--) { double const x = tile[i][r]; v2d const k = cs[i]; b = k.x * x - k.y * b; a = -k.y * a; }
+        seg[sub][r] = v2d{a, b};
+    }
+    // the originals that another half-wave overwrites: column `lo` (the left neighbour's first store) and the
+    // incoming carry of the whole recurrence (the first store of segment 0)
+    double const xlo = (hi >= lo) ? tile[lo][r] : 0.0;
+    double y = tile[ncol - 1][r];
+    __syncthreads();
+    for (int q = 0; q < sub; q++) { v2d const m = seg[q][r]; y = m.x * y + m.y; }
+    if (hi >= lo) {
+        int i = hi;
+        for (; i - 7 > lo; i -= 8) {
             double x[8]; v2d k[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) { x[q] = tile[i - q][r]; k[q] = cs[i - q]; }
@@ -485,13 +516,13 @@ __global__ __launch_bounds__(256) void ht_colpass_lds_kernel(double *__restrict_
                 y = k[q].x * x[q] - k[q].y * y;
             }
         }
-        for (; i >= 0; i--) {
-            double const x = tile[i][r];
+        for (; i >= lo; i--) {
+            double const x = (i == lo) ? xlo : tile[i][r];
             v2d const k = cs[i];
             tile[i + 1][r] = k.y * x + k.x * y;
             y = k.x * x - k.y * y;
         }
-        tile[0][r] = y;
+        if (lo == 0) tile[0][r] = y;
     }
     __syncthreads();
     if (rv) {
