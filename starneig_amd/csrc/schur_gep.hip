@@ -678,11 +678,17 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
 
     GepWorkspace &ws = g_gws;
     int const wmax = std::max({nw_conf + nw_conf / 2 + 8, small_limit, 2 * GWS});
-    // Shift multiplicity (see schur.hip).  Off by default for pencils: at n = 12000 a
-    // multiplicity of 4 cuts the time from 8.0 s to 6.1 s but the extra chain passes raise the
-    // residual from 460 u to 690 u (error ~ sqrt(number of 64-column window multiplications)),
-    // above the reference harness' 500 u warning line; SN_GEP_REUSE=k selects it.
-    int const reuse = tuning().gep_reuse;
+    // Shift multiplicity (see schur.hip): every shift pair of an AED drives `reuse` bulges of the following
+    // sweep.  Round 2 left it off for pencils -- at n = 12000 a multiplicity of 4 raised the residual from
+    // 460 u to 690 u then.  Since the reflectors are scaled by exact powers of two the extra chain passes
+    // cost nothing measurable (general pencil, Hessenberg-triangular reduction + QZ, multiplicity 1 / 4 / 8:
+    // n = 8000 QZ 2.18 / 0.99 / 0.74 s, 58 / 16 / 9 sweeps, chain residual 127 / 125 / 132 u; n = 3000
+    // 0.40 (2) / 0.29 / 0.24 s, 87 / 85 / 89 u; n = 1500 0.21 / 0.14 s (4), 73 / 68 u), so it is on:
+    // 4 below n = 2000, 8 above, from the fifth sweep on, capped so that a sweep carries at most ~450 bulges.
+    // SN_GEP_REUSE=k overrides.
+    int const reuse_env = tuning().gep_reuse;
+    int const reuse_n = n < 2000 ? 4 : 8;
+    int const reuse = reuse_env > 0 ? reuse_env : std::max(1, std::min(reuse_n, 450 / std::max(1, ns_conf / 2)));
     ws.ensure(n, wmax, reuse * (ns_conf / 2) + 1);
     GepDriver d{s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, ws, SchurStats{}};
     // the update kernel identifies "no Q" by a null pointer but still needs distinct slots
@@ -820,7 +826,9 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         }
         if (stagnation > 60) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
 
-        if (reuse > 1 && ihi - ilo > 4 * GWS) {
+        // (only once sweeps carry the reduction: the reference's ill-conditioned test pencil -- BASELINE config 5,
+        // two sweeps between 870 AEDs -- took 5 sweeps and 5 % longer with the multiplicity from the start)
+        if (reuse > 1 && iter >= 4 && ihi - ilo > 4 * GWS) {
             for (int r = 1; r < reuse; r++)
                 for (int k = 0; k < nshifts; k++) { sr[r * nshifts + k] = sr[k]; si[r * nshifts + k] = si[k]; }
             nshifts *= reuse;

@@ -35,7 +35,7 @@ struct Tuning {
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
-    int gep_reuse = 1;              // SN_GEP_REUSE
+    int gep_reuse = 0;              // SN_GEP_REUSE
     int gep_window = 0;             // SN_GEP_WINDOW: default AED window of the QZ path (0 = the built-in rule)
 };
 

@@ -41,7 +41,7 @@ Tuning const &tuning()
         t.gemm_nosplit = getb("SN_GEMM_NOSPLIT");
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
         t.gep_serial = getb("SN_GEP_SERIAL");
-        t.gep_reuse = std::max(1, std::min(8, geti("SN_GEP_REUSE", 1)));
+        t.gep_reuse = std::max(0, std::min(8, geti("SN_GEP_REUSE", 0)));
         t.gep_window = geti("SN_GEP_WINDOW", t.gep_window);
         return t;
     }();
