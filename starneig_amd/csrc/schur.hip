@@ -1192,12 +1192,13 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
     // chains only add `gap` steps each, so the same shifts applied 8x cost ~1.3x the time of a
     // sweep and cut the number of sweeps at n = 20000 from 81 to 13 (measured: 7.0 s -> 5.4 s at
     // a 192-row AED window).
-    // The extra chain passes buy little where sweeps are short anyway, so the multiplicity grows with
-    // the size: 2 below n = 4000, 4 below 12000, 8 above.  SN_SCHUR_REUSE=k overrides.
+    // Rounds 1-3 let the multiplicity grow with the size (2 below n = 4000, 4 below 12000, 8 above); measured
+    // again in round 4 (default / 8): n = 2000 0.16 / 0.14 s, n = 4000 0.24 / 0.22 s, n = 8000 0.51 / 0.45 s at
+    // 55 / 59 u -- 8 from n = 1000 on.  SN_SCHUR_REUSE=k overrides.
     int const reuse_env = tuning().schur_reuse;
     // (a conf with many shifts -- the reference's 0.06 n -- fills the sweep by itself: the multiplicity is
     // capped so that a sweep carries ~450 bulges, what 8 x 53 give at the default sizes)
-    int const reuse_n = n < 4000 ? 2 : (n < 12000 ? 4 : 8);
+    int const reuse_n = n < 1000 ? 2 : 8;
     int const reuse = reuse_env ? reuse_env : std::max(1, std::min(reuse_n, 450 / std::max(1, ns_conf / 2)));
     ws.ensure(n, wmax, divceil(reuse * (ns_conf / 2), NB_MAX) + 2);
     ws.guard_row = 0;
