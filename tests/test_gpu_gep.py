@@ -316,3 +316,32 @@ def test_right_threshold_decides_b_side_deflation(node, n):
     Q, Z = O.identity(n, ld=H.shape[0]), O.identity(n, ld=H.shape[0])
     assert node.GEP_SM_Schur_expert(conf, n, H, H.shape[0], R, R.shape[0], Q, Q.shape[0], Z, Z.shape[0],
                                     None, None, None) == node.INVALID_CONFIGURATION
+
+
+def test_general_pencil_chain_with_shift_multiplicity(node):
+    """A GENERAL pencil (two LCG matrices) through both generalized steps on the device: on its
+    Hessenberg-triangular form the QZ sweeps, not only the AED windows, carry the reduction, and every shift pair
+    of an AED drives several bulges from the fifth sweep on (csrc/schur_gep.hip; one bulge per pair took 13 sweeps
+    at n = 3000 with a multiplicity of 2 and more without).  The reference's acceptance checks on the whole chain."""
+    import torch
+    n = 3000
+    tA, tB = node.device_matrix(n), node.device_matrix(n)
+    assert node.lcg_fill_device(tA, n, n, seed=2019) == 0 and node.lcg_fill_device(tB, n, n, seed=77) == 0
+    tA0, tB0 = tA.clone(), tB.clone()
+    tQ, tZ = node.device_matrix(n), node.device_matrix(n)
+    node.set_matrix_device(tQ, n, n, 0.0, 1.0); node.set_matrix_device(tZ, n, n, 0.0, 1.0)
+    rc, _ = node.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+    assert rc == 0
+    rc, ar, ai, be, st = node.gep_schur_device(tA, tB, tQ, tZ, n=n)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert 4 < st["sweeps"] <= 10, st              # 4 sweeps with one bulge per pair, then few with eight
+    rc, ca = node.check_pencil_device(tQ, tA, tZ, tA0, n=n)
+    assert rc == 0
+    rc, cb = node.check_pencil_device(tQ, tB, tZ, tB0, n=n)
+    assert rc == 0
+    assert ca["residual_u"] < WARN_U and cb["residual_u"] < WARN_U
+    assert ca["orthogonality_q_u"] < WARN_U and ca["orthogonality_z_u"] < WARN_U
+    assert ca["below_subdiagonal"] == 0
+    assert O.check_gep_schur_form(to_host(tA), to_host(tB)) == 0
+    assert int((be == 0).sum()) == 0
