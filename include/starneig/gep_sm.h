@@ -38,8 +38,10 @@ starneig_error_t starneig_GEP_SM_Reduce(
  * Errors: n<1 -> -1, H NULL -> -2, ldH<n -> -3, R NULL -> -4, ldR<n -> -5, Q NULL -> -6,
  * ldQ<n -> -7, Z NULL -> -8, ldZ<n -> -9 (schur/interface.c:283-291; the checks stop there:
  * NULL real / imag / beta mean "eigenvalues not extracted", as in the reference);
- * STARNEIG_NOT_INITIALIZED; STARNEIG_DID_NOT_CONVERGE.  conf->right_threshold is accepted,
- * range-checked and not used. */
+ * STARNEIG_NOT_INITIALIZED; STARNEIG_DID_NOT_CONVERGE.  conf->right_threshold is honoured: it is
+ * the magnitude below which an entry of R is negligible in the window kernels (LAPACK dhgeqz's BTOL);
+ * a diagonal entry below it at the bottom of an active block is split off as an infinite
+ * eigenvalue with beta = 0. */
 starneig_error_t starneig_GEP_SM_Schur(
     int n, double H[], int ldH, double R[], int ldR,
     double Q[], int ldQ, double Z[], int ldZ,

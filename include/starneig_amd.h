@@ -40,7 +40,14 @@ starneig_error_t starneig_amd_hessenberg_device(
  * buffer 0 = dY, 1 = dP, 2 = dW, 3 = dA, 4 = dQ, ordered on `stream`
  * (torch.distributed over RCCL in starneig_amd/distributed.py).  With BOTH callbacks NULL the
  * collectives are issued to RCCL directly on `stream` (no host round trip per panel column), through
- * the communicator of starneig_amd_rccl_init. */
+ * the communicator of starneig_amd_rccl_init.
+ * stats (may be NULL) is double[8]: [0] total ms, [1] algorithmic bytes this rank's gemv launches
+ * streamed, [2] executed GEMM flops, [5] gemv launches.  With stats[7] = k >= 1 ON ENTRY the array is
+ * double[32] and every k-th gemv launch (with the all-reduce behind it) and every per-panel collective is
+ * timed with HIP events on `stream` (scaling report): [8] ms, [9] bytes, [10] count of the
+ * sampled launches; [11] per-column all-reduces issued; [12 + 3i .. 14 + 3i] ms, payload bytes, timed calls
+ * of collective kind i = 0 all-reduce of y (sampled columns), 1 panel broadcast, 2 all-reduce of W, 3 assembly
+ * of H and Q; [24] ranks of the library's RCCL communicator as ncclCommCount reports them (0: callbacks). */
 int starneig_amd_hessenberg_panel_ld(int n, int panel_width);
 
 /* RCCL called directly (librccl.so is opened at run time).  One communicator per process: rank 0
@@ -88,7 +95,7 @@ starneig_error_t starneig_amd_schur_rows_device(
  * T % world == r up to date and skips the others -- still no communication during the reduction.  On
  * return column tile T of the Schur form is valid on rank T % world only (the diagonal blocks, the
  * eigenvalues and everything left of them are valid everywhere); the caller assembles H from the
- * owners' tiles (starneig_amd/distributed.py: one broadcast per tile; node_team.hip: every rank copies
+ * owners' tiles (starneig_amd/distributed.py: one all-gather of the packed tiles; node_team.hip: every rank copies
  * its tiles back).  What the reference does by moving tiles between workers (schur/core.c:129-460
  * insert_updates over StarPU-MPI) is done here without moving anything until the end. */
 starneig_error_t starneig_amd_schur_sharded_device(

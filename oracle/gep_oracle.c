@@ -230,24 +230,132 @@ static int standardise(int n, int k, double *A, int lda, double *B, int ldb,
 
 /* (alpha_r + i alpha_i)/beta per diagonal position of a generalized Schur form
  * (the contract of starneig_extract_eigenvalues, schur/cpu_utils.c:3560-3594, GEP branch) */
+/* Eigenvalues of a 2 x 2 pencil (A, B), B upper triangular, as (wr1 + i wi) / scale1 and
+ * (wr2 - i wi) / scale2: LAPACK DLAG2 restated from its published algorithm (the reference calls it for
+ * every 2 x 2 block of a generalized Schur form: common/math.c:148-176, reached from the solver's
+ * eigenvalue extraction common/tasks.c:1134, schur/cpu_utils.c:3498 AND from the test hooks'
+ * test/common/checks.c:82 -- the same routine on the same block, which is why its `eigenvalues` hook
+ * holds to a few u).  C. Van Loan's method: the larger eigenvalue of A B^-1 shifted by the smaller of
+ * a11/b11, a22/b22, the smaller one from the determinant; scalings against over / underflow.
+ * Compiled without floating-point contraction: the product's host kernel (csrc/schur_host_gep.hip
+ * pencil2_dlag2) runs the same operations in the same order, and the two must agree to the last bit
+ * on a block whose discriminant nearly vanishes (a rounding there moves the pair by sqrt(u)).
+ * Pinned on LAPACK itself: tests/golden/dlag2_cases.npz (tests/golden/make_golden_dlag2.py). */
+__attribute__((optimize("fp-contract=off")))
+void oracle_dlag2(double const *A, int lda, double const *B, int ldb, double safmin,
+    double *scale1, double *scale2, double *wr1, double *wr2, double *wi)
+{
+    double const fuzzy1 = 1.0 + 1.0e-5;
+    double const rtmin = sqrt(safmin), rtmax = 1.0/rtmin, safmax = 1.0/safmin;
+    /* scale A */
+    double const anorm = MAX(MAX(fabs(A[0]) + fabs(A[1]), fabs(A[lda]) + fabs(A[lda+1])), safmin);
+    double const ascale = 1.0/anorm;
+    double const a11 = ascale*A[0], a21 = ascale*A[1], a12 = ascale*A[lda], a22 = ascale*A[lda+1];
+    /* perturb B if necessary to insure non-singularity */
+    double b11 = B[0], b12 = B[ldb], b22 = B[ldb+1];
+    double const bmin = rtmin*MAX(MAX(fabs(b11), fabs(b12)), MAX(fabs(b22), rtmin));
+    if (fabs(b11) < bmin) b11 = copysign(bmin, b11);
+    if (fabs(b22) < bmin) b22 = copysign(bmin, b22);
+    /* scale B */
+    double const bnorm = MAX(MAX(fabs(b11), fabs(b12) + fabs(b22)), safmin);
+    double const bsize = MAX(fabs(b11), fabs(b22));
+    double const bscale = 1.0/bsize;
+    b11 *= bscale; b12 *= bscale; b22 *= bscale;
+    /* larger eigenvalue (AS = A - shift B) */
+    double const binv11 = 1.0/b11, binv22 = 1.0/b22;
+    double const s1 = a11*binv11, s2 = a22*binv22;
+    double as12, abi22, pp, shift, ss;
+    if (fabs(s1) <= fabs(s2)) {
+        as12 = a12 - s1*b12;
+        double const as22 = a22 - s1*b22;
+        ss = a21*(binv11*binv22);
+        abi22 = as22*binv22 - ss*b12;
+        pp = 0.5*abi22;
+        shift = s1;
+    } else {
+        as12 = a12 - s2*b12;
+        double const as11 = a11 - s2*b11;
+        ss = a21*(binv11*binv22);
+        abi22 = -ss*b12;
+        pp = 0.5*(as11*binv11 + abi22);
+        shift = s2;
+    }
+    double const qq = ss*as12;
+    double discr, r;
+    if (fabs(pp*rtmin) >= 1.0) {
+        double const t = rtmin*pp;
+        discr = t*t + qq*safmin;
+        r = sqrt(fabs(discr))*rtmax;
+    } else if (pp*pp + fabs(qq) <= safmin) {
+        double const t = rtmax*pp;
+        discr = t*t + qq*safmax;
+        r = sqrt(fabs(discr))*rtmin;
+    } else {
+        discr = pp*pp + qq;
+        r = sqrt(fabs(discr));
+    }
+    if (discr >= 0.0 || r == 0.0) {
+        double const sr = copysign(r, pp);
+        double const sum = pp + sr, diff = pp - sr;
+        double const wbig = shift + sum;
+        double wsmall = shift + diff;
+        if (0.5*fabs(wbig) > MAX(fabs(wsmall), safmin)) {
+            double const wdet = (a11*a22 - a12*a21)*(binv11*binv22);
+            wsmall = wdet/wbig;
+        }
+        /* the (real) eigenvalue closest to the (2,2) element of A B^-1 goes to wr1 */
+        if (pp > abi22) { *wr1 = MIN(wbig, wsmall); *wr2 = MAX(wbig, wsmall); }
+        else { *wr1 = MAX(wbig, wsmall); *wr2 = MIN(wbig, wsmall); }
+        *wi = 0.0;
+    } else {
+        *wr1 = shift + pp; *wr2 = *wr1; *wi = r;
+    }
+    /* further scaling against under / overflow of scale1 and of w B */
+    double const c1 = bsize*(safmin*MAX(1.0, ascale));
+    double const c2 = safmin*MAX(1.0, bnorm);
+    double const c3 = bsize*safmin;
+    double const c4 = (ascale <= 1.0 && bsize <= 1.0) ? MIN(1.0, (ascale/safmin)*bsize) : 1.0;
+    double const c5 = (ascale <= 1.0 || bsize <= 1.0) ? MIN(1.0, ascale*bsize) : 1.0;
+    /* first eigenvalue */
+    double wabs = fabs(*wr1) + fabs(*wi);
+    double wsize = MAX(MAX(safmin, c1), MAX(fuzzy1*(wabs*c2 + c3), MIN(c4, 0.5*MAX(wabs, c5))));
+    if (wsize != 1.0) {
+        double const wscale = 1.0/wsize;
+        if (wsize > 1.0) *scale1 = (MAX(ascale, bsize)*wscale)*MIN(ascale, bsize);
+        else *scale1 = (MIN(ascale, bsize)*wscale)*MAX(ascale, bsize);
+        *wr1 *= wscale;
+        if (*wi != 0.0) { *wi *= wscale; *wr2 = *wr1; *scale2 = *scale1; }
+    } else {
+        *scale1 = ascale*bsize;
+        *scale2 = *scale1;
+    }
+    /* second eigenvalue, if real */
+    if (*wi == 0.0) {
+        wabs = fabs(*wr2);
+        wsize = MAX(MAX(safmin, c1), MAX(fuzzy1*(wabs*c2 + c3), MIN(c4, 0.5*MAX(wabs, c5))));
+        if (wsize != 1.0) {
+            double const wscale = 1.0/wsize;
+            if (wsize > 1.0) *scale2 = (MAX(ascale, bsize)*wscale)*MIN(ascale, bsize);
+            else *scale2 = (MIN(ascale, bsize)*wscale)*MAX(ascale, bsize);
+            *wr2 *= wscale;
+        } else *scale2 = ascale*bsize;
+    }
+}
+
+/* The eigenvalues (real, imag, beta) of a generalized real Schur form read off its diagonal blocks, as
+ * the reference's test hooks do (test/common/checks.c:59-100 eigenvalue_crawler): a 1 x 1 block gives
+ * (S(i,i), 0, T(i,i)), a 2 x 2 block goes through DLAG2 (compute_complex_eigenvalue, common/math.c:148-176:
+ * real = wr, imag = +-wi, beta = scale). */
 void oracle_gep_extract_eigenvalues(int n, double const *S, int lds, double const *T, int ldt,
     double *ar, double *ai, double *be)
 {
     int k = 0;
     while (k < n) {
         if (k+1 < n && EL(S,lds,k+1,k) != 0.0) {
-            double a11 = EL(S,lds,k,k), a12 = EL(S,lds,k,k+1), a21 = EL(S,lds,k+1,k), a22 = EL(S,lds,k+1,k+1);
-            double b11 = EL(T,ldt,k,k), b12 = EL(T,ldt,k,k+1), b22 = EL(T,ldt,k+1,k+1);
-            double p = b11*b22, q = a11*b22 + a22*b11 - a21*b12, r = a11*a22 - a12*a21;
-            double disc = q*q - 4.0*p*r;
-            double re = q/(2.0*p), im = sqrt(fabs(disc))/(2.0*fabs(p));
-            if (disc >= 0.0) { /* not standardised; report the real pair */
-                ar[k] = re + im; ai[k] = 0.0; be[k] = 1.0;
-                ar[k+1] = re - im; ai[k+1] = 0.0; be[k+1] = 1.0;
-            } else {
-                ar[k] = re*b11; ai[k] = im*b11; be[k] = b11;
-                ar[k+1] = re*b22; ai[k+1] = -im*b22; be[k+1] = b22;
-            }
+            double s1, s2, w1, w2, wi;
+            oracle_dlag2(&EL(S,lds,k,k), lds, &EL(T,ldt,k,k), ldt, DBL_MIN, &s1, &s2, &w1, &w2, &wi);
+            ar[k] = w1; ai[k] = wi; be[k] = s1;
+            ar[k+1] = w2; ai[k+1] = -wi; be[k+1] = s2;
             k += 2;
         } else {
             ar[k] = EL(S,lds,k,k); ai[k] = 0.0; be[k] = EL(T,ldt,k,k);

@@ -211,6 +211,23 @@ def gep_extract_eigenvalues(S, T):
     return ar, ai, be
 
 
+def dlag2(A, B):
+    """LAPACK DLAG2 restated (oracle/gep_oracle.c:oracle_dlag2): (scale1, scale2, wr1, wr2, wi) of the
+    2 x 2 pencil (A, B), B upper triangular."""
+    a = np.asfortranarray(A, dtype=np.float64); b = np.asfortranarray(B, dtype=np.float64)
+    out = np.zeros(5)
+    dp = C.POINTER(C.c_double)
+    L = lib()
+    L.oracle_dlag2.argtypes = [dp, C.c_int, dp, C.c_int, C.c_double, dp, dp, dp, dp, dp]
+    L.oracle_dlag2.restype = None
+    o = out.ctypes.data_as(dp)
+    L.oracle_dlag2(a.ctypes.data_as(dp), 2, b.ctypes.data_as(dp), 2, float(np.finfo(np.float64).tiny),
+                   C.cast(C.addressof(o.contents), dp), C.cast(C.addressof(o.contents) + 8, dp),
+                   C.cast(C.addressof(o.contents) + 16, dp), C.cast(C.addressof(o.contents) + 24, dp),
+                   C.cast(C.addressof(o.contents) + 32, dp))
+    return out
+
+
 def check_gep_schur_form(S, T):
     return lib().oracle_check_gep_schur_form(S.shape[1], _p(S), S.shape[0], _p(T), T.shape[0])
 

@@ -899,11 +899,23 @@ SN_API starneig_error_t starneig_amd_hessenberg_sharded_device(
     sn::HessComm comm{rank, world, native ? native_allreduce : allreduce_sum, native ? native_broadcast : broadcast,
                       native ? (void *)&nc : ctx};
     sn::HessenbergTimings tm;
+    // stats[7] > 0 on entry: `stats` holds 32 doubles and every stats[7]-th gemv launch (with its all-reduce)
+    // and every per-panel collective is event-timed (include/starneig_amd.h)
+    bool const detailed = stats && stats[7] >= 1.0;
+    if (detailed) tm.sample_every = (int)stats[7];
     int rc = sn::hessenberg_sharded_device(s, n, panel_width, dA, ldA, dQ, ldQ, dY, dP, dW,
         w_capacity, comm, stats ? &tm : nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(s));
     if (stats) { stats[0] = tm.total_ms; stats[1] = tm.gemv_bytes; stats[2] = tm.gemm_flops;
                  stats[5] = (double)tm.gemv_launches; }
+    if (detailed) {
+        stats[8] = tm.sampled_ms; stats[9] = tm.sampled_bytes; stats[10] = (double)tm.sampled_launches;
+        stats[11] = (double)tm.allreduce_y_calls;
+        for (int k = 0; k < 4; k++) {
+            stats[12 + 3 * k] = tm.comm_ms[k]; stats[13 + 3 * k] = tm.comm_bytes[k]; stats[14 + 3 * k] = (double)tm.comm_calls[k];
+        }
+        stats[24] = sn::rccl_comm_count();
+    }
     return rc == 0 ? STARNEIG_SUCCESS : STARNEIG_GENERIC_ERROR;
 }
 

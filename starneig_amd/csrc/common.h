@@ -69,6 +69,14 @@ struct HessenbergTimings {
     long sampled_launches = 0;
     double sampled_bytes = 0.0; // algorithmic bytes of the sampled launches
     double sampled_ms = 0.0;    // their summed kernel durations
+    // sharded reduction only (SURVEY 8d "scaling report"): the collectives by kind, event-timed on the
+    // reduction's stream -- [0] per-column all-reduce of y (the SAMPLED columns only), [1] per-panel
+    // broadcast of the panel columns, [2] per-panel all-reduce of W (rows above the panel), [3] assembly of
+    // H and Q at the end (broadcasts, one per block column / row block chunk)
+    double comm_ms[4] = {0, 0, 0, 0};
+    double comm_bytes[4] = {0, 0, 0, 0};    // payload bytes of the timed calls (count * 8)
+    long comm_calls[4] = {0, 0, 0, 0};      // timed calls (for [0]: the sampled ones)
+    long allreduce_y_calls = 0;             // all per-column all-reduces issued
 };
 
 // Reduces columns [begin,end) of the device-resident n x n matrix dA (ld ldA)
@@ -95,6 +103,7 @@ int rccl_unique_id(void *id128);
 int rccl_init(int rank, int world, void const *id128);
 void rccl_finalize();
 bool rccl_ready(int rank, int world);
+int rccl_comm_count();
 int rccl_allreduce_sum(double *buf, long count, hipStream_t s);
 int rccl_broadcast(double *buf, long count, int root, hipStream_t s);
 

@@ -245,6 +245,21 @@ void dgemm_right_inplace(hipStream_t s, int nrows, int w, double const *U, int l
     launch<128, 128, 16, false, false>(s, nrows, w, w, 1.0, X, ldx, U, ldu, 0.0, X, ldx);
 }
 
+// k <= 0: the product is empty, C <- beta C (BLAS semantics).  The tile kernels load their boundary k-tiles
+// from clamped addresses min(k0 + kk, k - 1) and must never see k = 0.
+__global__ void dgemm_scale_kernel(int m, int n, double beta, double *__restrict__ C, int ldc)
+{
+    int const r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    for (int c = blockIdx.y; c < n; c += gridDim.y) C[(size_t)c * ldc + r] *= beta;
+}
+static void empty_product(hipStream_t s, int m, int n, double beta, double *C, int ldc)
+{
+    if (beta == 1.0) return;
+    if (beta == 0.0) { SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s)); return; }
+    hipLaunchKernelGGL(dgemm_scale_kernel, dim3(divceil(m, 256), std::min(n, 1024)), dim3(256), 0, s, m, n, beta, C, ldc);
+}
+
 // C = op(A) op(B) with 128 x 64 tiles and two-level summation whatever the shape: the acceptance
 // checks (||Q Q^T - I||, ||Q H Q^T - A||) must not add rounding noise of their own -- a single
 // chain over k = n = 20000 costs ~10 u on the diagonal of Q Q^T
@@ -252,6 +267,7 @@ void dgemm_accurate(hipStream_t s, char transA, char transB, int m, int n, int k
     double const *A, int lda, double const *B, int ldb, double *C, int ldc)
 {
     if (m <= 0 || n <= 0) return;
+    if (k <= 0) { empty_product(s, m, n, 0.0, C, ldc); return; }
     bool ta = (transA == 'T' || transA == 't'), tb = (transB == 'T' || transB == 't');
     if (ta && tb)        launch<128, 64, 16, true, true>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
     else if (ta && !tb)  launch<128, 64, 16, true, false>(s, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc);
@@ -264,6 +280,7 @@ void dgemm(hipStream_t s, char transA, char transB, int m, int n, int k,
     double beta, double *C, int ldc)
 {
     if (m <= 0 || n <= 0) return;
+    if (k <= 0 || alpha == 0.0) { empty_product(s, m, n, beta, C, ldc); return; }
     bool ta = (transA == 'T' || transA == 't');
     bool tb = (transB == 'T' || transB == 't');
     if (ta && tb)        dispatch<true, true>(s, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);

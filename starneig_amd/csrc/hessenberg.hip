@@ -326,7 +326,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
     double const *__restrict__ Y, double *__restrict__ t12,
     double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
-    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr)
+    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr, int fold = 0)
 {
     __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_t[3][NGS][RBS + 1], s_scal[2];
     __shared__ int s_last;
@@ -455,13 +455,30 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             if (g >= R0) yp[g] = f0 + scale * (a0 + b0);
             if (g + 1 >= R0 && g + 1 < E) yp[g + 1] = f1 + scale * (a1 + b1);
         } else {
+            // Hand-off of the column-split partials to the workgroup that takes the tile's LAST ticket
+            // (cdna_hip_programming.md section 6, Guideline 16, counter form): every partial is stored
+            // write-through (sc1) and drained by its wave, the workgroup meets at its barrier, one lane
+            // RELEASES at agent scope, takes the ticket, and the last arriver ACQUIRES at agent scope
+            // before any wave of it loads a partial (sc1 loads as well).  Rounds 3-4 relied on the sc1
+            // accesses alone (fold == 1; measured valid only for one workgroup per CU -- this launch
+            // keeps ~5 resident); the explicit release / acquire is correct for any placement.
             if (g >= R0 && g < E) __hip_atomic_store(yp + g, f0 + scale * (a0 + b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (g + 1 >= R0 && g + 1 < E) __hip_atomic_store(yp + g + 1, f1 + scale * (a1 + b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int const nsplit = ((int)gridDim.x - nshadow) / row_tiles;
-            if (threadIdx.x == 0)
-                s_last = __hip_atomic_fetch_add(tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+            if (threadIdx.x == 0) {
+                if (fold != 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler
+                }
+                int const last = __hip_atomic_fetch_add(tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
+                if (last && fold != 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // holds the barrier below until the invalidate is through
+                }
+                s_last = last;
+            }
             __syncthreads();
             if (s_last) {
                 #pragma unroll
@@ -527,6 +544,9 @@ struct HessWorkspace {
     std::vector<hipEvent_t> gemm_ev;        // per panel: (start, stop) of the critical and of the side updates
     std::vector<hipEvent_t> sample_ev;      // pairs (start, stop) around sampled gemv launches
     std::vector<double> sample_bytes;
+    std::vector<hipEvent_t> comm_ev;        // sharded reduction: pairs around the timed collectives
+    std::vector<int> comm_kind;
+    std::vector<double> comm_payload;
 
     void release() {
         double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal, &t12};
@@ -544,7 +564,8 @@ struct HessWorkspace {
         for (int k = 0; k < 2; k++) { kill(panel_done[k]); kill(side_done[k]); }
         for (hipEvent_t &e : gemm_ev) kill(e);
         for (hipEvent_t &e : sample_ev) kill(e);
-        gemm_ev.clear(); sample_ev.clear();
+        for (hipEvent_t &e : comm_ev) kill(e);
+        gemm_ev.clear(); sample_ev.clear(); comm_ev.clear();
     }
     void ensure(int n_, int nb_) {
         int const need_splits = std::max(MAX_SPLIT, divceil(n_, std::max(8, nb_)) + 1);
@@ -870,7 +891,38 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     if ((long)n * panel_width > w2_capacity) return -1;
     // with one rank there is nothing to reduce: the column chain reads the gemv's partials directly
     bool const reduce_y = world > 1;
+    // how the column-split partials of the sharded gemv are folded: 0 in the launch, by the last workgroup of
+    // each row tile behind an agent-scope release / acquire; 1 the same on sc1 accesses alone (rounds 3-4, kept
+    // for the reproducer of tests/test_gpu_node_team.py); 2 by a launch of its own
+    int const fold = tuning().hess_fold;
     if (reduce_y && aligned) SN_HIP_CHECK(hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * HessWorkspace::MAX_ROW_TILES, s));
+    // measurement (bench.py at N > 1): HIP events on the reduction's stream around every k-th gemv launch
+    // and its all-reduce, around the per-panel collectives and the assembly
+    int const sample_every = tm ? tm->sample_every : 0;
+    size_t nsampled = 0, ncomm = 0;
+    long allreduce_y_calls = 0;
+    ws.sample_bytes.clear(); ws.comm_kind.clear(); ws.comm_payload.clear();
+    auto sample_begin = [&]() {
+        if (ws.sample_ev.size() < 2 * (nsampled + 1)) {
+            hipEvent_t a, b;
+            SN_HIP_CHECK(hipEventCreate(&a)); SN_HIP_CHECK(hipEventCreate(&b));
+            ws.sample_ev.push_back(a); ws.sample_ev.push_back(b);
+        }
+        SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled], s));
+    };
+    auto comm_begin = [&]() {
+        if (ws.comm_ev.size() < 2 * (ncomm + 1)) {
+            hipEvent_t a, b;
+            SN_HIP_CHECK(hipEventCreate(&a)); SN_HIP_CHECK(hipEventCreate(&b));
+            ws.comm_ev.push_back(a); ws.comm_ev.push_back(b);
+        }
+        SN_HIP_CHECK(hipEventRecord(ws.comm_ev[2 * ncomm], s));
+    };
+    auto comm_end = [&](int kind, double payload) {
+        SN_HIP_CHECK(hipEventRecord(ws.comm_ev[2 * ncomm + 1], s));
+        ws.comm_kind.push_back(kind); ws.comm_payload.push_back(payload); ncomm++;
+    };
+    bool const time_comm = sample_every > 0 && world > 1;
 
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
     int pcount = 0;
@@ -889,7 +941,11 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
         // panel columns from their owner (the caller's dP is the panel buffer of every rank)
         hipLaunchKernelGGL(hess_copy_in_kernel, dim3(divceil(m, 256), nb), dim3(256), 0, s,
             R0, E, nb, i, dA, ldA, dP, ldp);
-        if (world > 1) comm.broadcast(comm.ctx, 1, 0, (long)ldp * nb, owner);
+        if (world > 1) {
+            if (time_comm) comm_begin();
+            comm.broadcast(comm.ctx, 1, 0, (long)ldp * nb, owner);
+            if (time_comm) comm_end(1, 8.0 * ldp * nb);
+        }
 
         int nsplit = 0;
         for (int j = 0; j < nb; j++) {
@@ -909,10 +965,16 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             int const nshadow = divceil(m, RBS);
             if (nsplit > ws.ysplits || row_tiles > HessWorkspace::MAX_ROW_TILES) return -2;
             dim3 grid(nshadow + row_tiles * nsplit);
-            if (aligned && reduce_y)
+            // this rank's share of the column's bytes: its owned blocks cut to [piv, E)
+            double own_cols = 0.0;
+            for (int B = first; B <= last_block; B += world)
+                own_cols += std::min(E, (B + 1) * cb) - std::max(piv, B * cb);
+            bool const sampled = sample_every > 0 && (gemv_launches % sample_every) == 0;
+            if (sampled) sample_begin();
+            if (aligned && reduce_y && fold != 2)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, true, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
-                    world, rank, dYsum, ws.tile_cnt);
+                    world, rank, dYsum, ws.tile_cnt, fold);
             else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
@@ -923,13 +985,23 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                     world, rank);
             if (reduce_y) {
                 if (nsplit == 0) SN_HIP_CHECK(hipMemsetAsync(dYsum + R0, 0, (size_t)m * sizeof(double), s));
-                else if (!aligned)
+                else if (!aligned || fold == 2)
                     hipLaunchKernelGGL(hess_ysum_kernel, dim3(divceil(m, 256)), dim3(256), 0, s,
                         R0, E, nsplit, ldp, ws.ypart, dYsum);
+                if (sampled) {      // the fold is part of the launch (fold 0 / 1) or stands right behind it (fold 2)
+                    SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
+                    ws.sample_bytes.push_back(8.0 * (double)m * own_cols); nsampled++;
+                }
+                if (sampled && time_comm) comm_begin();
                 comm.allreduce_sum(comm.ctx, 0, R0, (long)m);
+                if (sampled && time_comm) comm_end(0, 8.0 * m);
+                allreduce_y_calls++;
+            } else if (sampled) {
+                SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
+                ws.sample_bytes.push_back(8.0 * (double)m * own_cols); nsampled++;
             }
             gemv_launches++;
-            gemv_bytes += 8.0 * (double)m * (double)(E - piv) / world;
+            gemv_bytes += 8.0 * (double)m * own_cols;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
             R0, E, nb, ldp, dP, V, Ys, reduce_y ? dYsum : ws.ypart, reduce_y ? 1 : nsplit, ws.acc, ws.scal);
@@ -981,7 +1053,11 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                 gemm_flops += 2.0 * R0 * (double)nt * nb;
             }
             if (first_run) SN_HIP_CHECK(hipMemsetAsync(dW2, 0, (size_t)R0 * nb * sizeof(double), us));
-            if (world > 1) comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
+            if (world > 1) {
+                if (time_comm) comm_begin();
+                comm.allreduce_sum(comm.ctx, 2, 0, (long)R0 * nb);
+                if (time_comm) comm_end(2, 8.0 * R0 * nb);
+            }
             for (int B = R0 / cb; B * cb < E; ) {
                 if (B % world != rank) { B++; continue; }
                 int B1 = B + 1;
@@ -1010,9 +1086,12 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     // broadcasts: the block columns of A are contiguous; the row blocks of Q go through dW2 in chunks of
     // columns) -- instead of zeroing the rest and all-reducing two full matrices
     if (world > 1) {
+        double assembled = 0.0;
+        if (time_comm) comm_begin();
         for (int B = 0; B * cb < n; B++) {
             int const c0 = B * cb, c1 = std::min(n, c0 + cb);
             comm.broadcast(comm.ctx, 3, (long)c0 * ldA, (long)(c1 - c0) * ldA, B % world);
+            assembled += 8.0 * (c1 - c0) * ldA;
         }
         if (dQ) {
             for (int root = 0; root < world; root++) {
@@ -1025,11 +1104,13 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                     if (root == rank)
                         hipLaunchKernelGGL(hess_pack_rows_kernel, grid, dim3(256), 0, s, 0, r_lo, r_hi, c0, nc, dQ, ldQ, dW2);
                     comm.broadcast(comm.ctx, 2, 0, (long)rows * nc, root);
+                    assembled += 8.0 * rows * nc;
                     if (root != rank)
                         hipLaunchKernelGGL(hess_pack_rows_kernel, grid, dim3(256), 0, s, 1, r_lo, r_hi, c0, nc, dQ, ldQ, dW2);
                 }
             }
         }
+        if (time_comm) comm_end(3, assembled);
     }
     if (tm) {
         SN_HIP_CHECK(hipEventRecord(ws.ev1, s));
@@ -1040,6 +1121,21 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
         tm->gemv_bytes = gemv_bytes;
         tm->gemm_flops = gemm_flops;
         tm->gemv_launches = gemv_launches;
+        tm->sampled_launches = (long)nsampled;
+        tm->sampled_bytes = 0.0; tm->sampled_ms = 0.0;
+        for (size_t k = 0; k < nsampled; k++) {
+            float t = 0.f;
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.sample_ev[2 * k], ws.sample_ev[2 * k + 1]));
+            tm->sampled_ms += t; tm->sampled_bytes += ws.sample_bytes[k];
+        }
+        for (int k = 0; k < 4; k++) { tm->comm_ms[k] = 0.0; tm->comm_bytes[k] = 0.0; tm->comm_calls[k] = 0; }
+        for (size_t k = 0; k < ncomm; k++) {
+            float t = 0.f;
+            SN_HIP_CHECK(hipEventElapsedTime(&t, ws.comm_ev[2 * k], ws.comm_ev[2 * k + 1]));
+            int const kind = ws.comm_kind[k];
+            tm->comm_ms[kind] += t; tm->comm_bytes[kind] += ws.comm_payload[k]; tm->comm_calls[kind]++;
+        }
+        tm->allreduce_y_calls = allreduce_y_calls;
     }
     return 0;
 }

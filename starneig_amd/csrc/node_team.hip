@@ -37,6 +37,33 @@ namespace {
 
 constexpr int MAX_RANKS = 16;
 
+// A failed allocation on one rank is an error code of the call, not an abort of the caller's process
+// (VERDICT round 4): the ranks record it, meet at a barrier and leave together.
+#define SN_TEAM_TRY(expr, failures)                                             \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            fprintf(stderr, "[starneig-amd] rank %d: %s at %s:%d: %s\n", rank, hipGetErrorName(e_), \
+                __FILE__, __LINE__, hipGetErrorString(e_));                     \
+            (void)hipGetLastError(); (failures)++;                              \
+        }                                                                       \
+    } while (0)
+
+// what one rank needs on its device for a sharded reduction of an n x n matrix: its two full-size
+// buffers, the cached panel workspaces (a generous 35 % of two matrices) and 1 GB of slack
+bool rank_fits(int rank, int n)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
+    if (tuning().team_fail_rank == rank) free_b = 0;    // tests: this rank "cannot allocate"
+    double const mat = (double)roundup(n, 16) * n * sizeof(double);
+    double const need = 2 * mat + 0.7 * mat + 1e9;
+    if (need <= (double)free_b) return true;
+    fprintf(stderr, "[starneig-amd] rank %d: n = %d needs about %.1f GB of device memory, %.1f GB are free\n",
+        rank, n, need / 1e9, (double)free_b / 1e9);
+    return false;
+}
+
 struct PtrTable { double const *p[MAX_RANKS]; };
 
 // out[i] = sum over ranks (in rank order) of src[r][i]
@@ -140,11 +167,22 @@ struct Team {
             }
         }
         if (!use_rccl && distinct && world > 1) {
-            // the in-process exchange reads peer memory from kernels
+            // the in-process exchange reads peer memory from kernels: every pair must be reachable
+            std::atomic<int> unreachable{0};
             run([&](int rank) {
-                for (int r = 0; r < world; r++)
-                    if (r != rank) { hipError_t e = hipDeviceEnablePeerAccess(device[r], 0); (void)e; (void)hipGetLastError(); }
+                for (int r = 0; r < world; r++) {
+                    if (r == rank) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, device[rank], device[r]) != hipSuccess || !can) { unreachable++; continue; }
+                    hipError_t const e = hipDeviceEnablePeerAccess(device[r], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) unreachable++;
+                    (void)hipGetLastError();
+                }
             });
+            if (unreachable.load() > 0) {
+                fprintf(stderr, "[starneig-amd] no RCCL and no peer access between the devices: the calls stay on one GPU\n");
+                stop();
+            }
         }
     }
     void stop()
@@ -188,7 +226,10 @@ struct Team {
     }
 };
 
-Team g_team;
+// A heap singleton that is never destroyed: a process that leaves without starneig_node_finalize must not
+// run into the destructor of joinable threads (std::terminate) during static destruction.
+Team &team() { static Team *t = new Team; return *t; }
+#define g_team (team())
 
 struct RankComm { Team *team; int rank; double *buf[5]; hipStream_t s; };
 void team_allreduce_cb(void *ctx, int buffer, long offset, long count)
@@ -231,10 +272,21 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
         hipStream_t s = T.stream[rank];
         size_t const bytes = (size_t)ld * n * 8;
         double *dA = nullptr, *dQ = nullptr, *dY = nullptr, *dP = nullptr, *dW = nullptr;
-        SN_HIP_CHECK(hipMalloc((void **)&dA, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
-        SN_HIP_CHECK(hipMalloc((void **)&dY, (size_t)ldp * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dP, (size_t)ldp * panel_width * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dW, (size_t)n * panel_width * 8));
+        // allocation phase: a rank that cannot get its buffers records the failure, everybody meets at the
+        // barrier and the whole team leaves before the first collective (STARNEIG_GENERIC_ERROR)
+        if (!rank_fits(rank, n)) failures++;
+        else {
+            SN_TEAM_TRY(hipMalloc((void **)&dA, bytes), failures);
+            SN_TEAM_TRY(hipMalloc((void **)&dQ, bytes), failures);
+            SN_TEAM_TRY(hipMalloc((void **)&dY, (size_t)ldp * 8), failures);
+            SN_TEAM_TRY(hipMalloc((void **)&dP, (size_t)ldp * panel_width * 8), failures);
+            SN_TEAM_TRY(hipMalloc((void **)&dW, (size_t)n * panel_width * 8), failures);
+        }
+        T.bar.wait();
+        if (failures.load() > 0) {
+            for (double *p : {dA, dQ, dY, dP, dW}) if (p) (void)hipFree(p);
+            return;
+        }
         SN_HIP_CHECK(hipMemsetAsync(dA, 0, bytes, s)); SN_HIP_CHECK(hipMemsetAsync(dQ, 0, bytes, s));
         SN_HIP_CHECK(hipMemsetAsync(dY, 0, (size_t)ldp * 8, s));
         SN_HIP_CHECK(hipMemsetAsync(dP, 0, (size_t)ldp * panel_width * 8, s));
@@ -249,10 +301,13 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
             (long)n * panel_width, comm, nullptr);
         SN_HIP_CHECK(hipStreamSynchronize(s));
         if (r != 0) failures++;
-        int const per = divceil(n, world), c0 = std::min(n, rank * per), c1 = std::min(n, c0 + per);
-        if (c1 > c0) {
-            download_host_matrix(A + (size_t)c0 * ldA, ldA, dA + (size_t)c0 * ld, ld, n, c1 - c0, threads);
-            download_host_matrix(Q + (size_t)c0 * ldQ, ldQ, dQ + (size_t)c0 * ld, ld, n, c1 - c0, threads);
+        T.bar.wait();                                   // a failed rank: nobody overwrites the caller's arrays
+        if (failures.load() == 0) {
+            int const per = divceil(n, world), c0 = std::min(n, rank * per), c1 = std::min(n, c0 + per);
+            if (c1 > c0) {
+                download_host_matrix(A + (size_t)c0 * ldA, ldA, dA + (size_t)c0 * ld, ld, n, c1 - c0, threads);
+                download_host_matrix(Q + (size_t)c0 * ldQ, ldQ, dQ + (size_t)c0 * ld, ld, n, c1 - c0, threads);
+            }
         }
         for (double *p : {dA, dQ, dY, dP, dW}) SN_HIP_CHECK(hipFree(p));
     });
@@ -275,13 +330,19 @@ int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real,
     std::vector<int> rcs(world, 0);
     std::vector<std::vector<double>> wr(world), wi(world), chk(world);
     std::vector<double *> dHs(world, nullptr), dQs(world, nullptr);
+    std::atomic<int> alloc_failures{0};
     T.run([&](int rank) {
         int const r0 = std::min(n, rank * qchunk), r1 = std::min(n, (rank + 1) * qchunk), rows = r1 - r0;
         if (rows <= 0) return;
         hipStream_t s = T.stream[rank];
         size_t const bytes = (size_t)ld * n * 8;
         double *dH = nullptr, *dQ = nullptr;
-        SN_HIP_CHECK(hipMalloc((void **)&dH, bytes)); SN_HIP_CHECK(hipMalloc((void **)&dQ, bytes));
+        // no collective inside this leg: a rank that cannot allocate drops out by itself and the call
+        // returns STARNEIG_GENERIC_ERROR without touching the caller's arrays
+        if (!rank_fits(rank, n)) { alloc_failures++; return; }
+        SN_TEAM_TRY(hipMalloc((void **)&dH, bytes), alloc_failures);
+        SN_TEAM_TRY(hipMalloc((void **)&dQ, bytes), alloc_failures);
+        if (!dH || !dQ) { if (dH) (void)hipFree(dH); if (dQ) (void)hipFree(dQ); return; }
         SN_HIP_CHECK(hipMemsetAsync(dH, 0, bytes, s)); SN_HIP_CHECK(hipMemsetAsync(dQ, 0, bytes, s));
         SN_HIP_CHECK(hipStreamSynchronize(s));
         upload_host_matrix(dH, ld, H, ldH, n, n, threads);
@@ -306,7 +367,8 @@ int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real,
         if (first < 0) { first = r; rc = rcs[r]; continue; }
         if (std::memcmp(chk[r].data(), chk[first].data(), chk[r].size() * 8) != 0) same = false;
     }
-    if (!same) {
+    if (alloc_failures.load() > 0) { same = false; rc = 1; }
+    else if (!same) {
         fprintf(stderr, "[starneig-amd] the replicas of H diverged in the sharded Schur leg; nothing was written back\n");
         rc = 1;     // STARNEIG_GENERIC_ERROR
     }

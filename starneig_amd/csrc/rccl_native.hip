@@ -98,6 +98,16 @@ void rccl_finalize()
     g_comm.rank = -1; g_comm.world = 0;
 }
 
+// ranks of the calling thread's communicator as RCCL itself reports them (ncclCommCount), 0 without one
+int rccl_comm_count()
+{
+    if (!g_comm.comm) return 0;
+    auto count = (ncclResult_t (*)(ncclComm_t, int *))dlsym(g_rccl->handle, "ncclCommCount");
+    int c = 0;
+    if (!count || count(g_comm.comm, &c) != ncclSuccess) return -1;
+    return c;
+}
+
 bool rccl_ready(int rank, int world) { return g_comm.comm && g_comm.rank == rank && g_comm.world == world; }
 
 int rccl_allreduce_sum(double *buf, long count, hipStream_t s)

@@ -232,6 +232,107 @@ inline bool pencil2_eigenvalues(double a11, double a12, double a21, double a22,
     return false;
 }
 
+// (alpha_r + i alpha_i, beta) of the two eigenvalues of a 2 x 2 pencil as the reference RETURNS them:
+// LAPACK dlag2's outputs real = wr, imag = +-wi, beta = scale (common/math.c:148-176; dlag2 restated from
+// its published algorithm, scalings included).  The test hook evaluates the same routine on the same
+// block (test/common/checks.c:82), and on a block whose discriminant nearly vanishes one rounding moves
+// the pair by sqrt(u): no floating-point contraction here, so that this function, the test suite's own
+// restatement and LAPACK itself give the same bits (tests/golden/dlag2_cases.npz).
+void pencil2_dlag2(double const *A, int lda, double const *B, int ldb,
+    double &scale1, double &scale2, double &wr1, double &wr2, double &wi)
+{
+#pragma clang fp contract(off)
+    double const safmin = DBL_MIN, fuzzy1 = 1.0 + 1.0e-5;
+    double const rtmin = std::sqrt(safmin), rtmax = 1.0 / rtmin, safmax = 1.0 / safmin;
+    auto mx = [](double a, double b) { return a > b ? a : b; };
+    auto mn = [](double a, double b) { return a < b ? a : b; };
+    double const anorm = mx(mx(std::fabs(A[0]) + std::fabs(A[1]), std::fabs(A[lda]) + std::fabs(A[lda + 1])), safmin);
+    double const ascale = 1.0 / anorm;
+    double const a11 = ascale * A[0], a21 = ascale * A[1], a12 = ascale * A[lda], a22 = ascale * A[lda + 1];
+    double b11 = B[0], b12 = B[ldb], b22 = B[ldb + 1];
+    double const bmin = rtmin * mx(mx(std::fabs(b11), std::fabs(b12)), mx(std::fabs(b22), rtmin));
+    if (std::fabs(b11) < bmin) b11 = std::copysign(bmin, b11);
+    if (std::fabs(b22) < bmin) b22 = std::copysign(bmin, b22);
+    double const bnorm = mx(mx(std::fabs(b11), std::fabs(b12) + std::fabs(b22)), safmin);
+    double const bsize = mx(std::fabs(b11), std::fabs(b22));
+    double const bscale = 1.0 / bsize;
+    b11 *= bscale; b12 *= bscale; b22 *= bscale;
+    double const binv11 = 1.0 / b11, binv22 = 1.0 / b22;
+    double const s1 = a11 * binv11, s2 = a22 * binv22;
+    double as12, abi22, pp, shift, ss;
+    if (std::fabs(s1) <= std::fabs(s2)) {
+        as12 = a12 - s1 * b12;
+        double const as22 = a22 - s1 * b22;
+        ss = a21 * (binv11 * binv22);
+        abi22 = as22 * binv22 - ss * b12;
+        pp = 0.5 * abi22;
+        shift = s1;
+    } else {
+        as12 = a12 - s2 * b12;
+        double const as11 = a11 - s2 * b11;
+        ss = a21 * (binv11 * binv22);
+        abi22 = -ss * b12;
+        pp = 0.5 * (as11 * binv11 + abi22);
+        shift = s2;
+    }
+    double const qq = ss * as12;
+    double discr, r;
+    if (std::fabs(pp * rtmin) >= 1.0) {
+        double const t = rtmin * pp;
+        discr = t * t + qq * safmin;
+        r = std::sqrt(std::fabs(discr)) * rtmax;
+    } else if (pp * pp + std::fabs(qq) <= safmin) {
+        double const t = rtmax * pp;
+        discr = t * t + qq * safmax;
+        r = std::sqrt(std::fabs(discr)) * rtmin;
+    } else {
+        discr = pp * pp + qq;
+        r = std::sqrt(std::fabs(discr));
+    }
+    if (discr >= 0.0 || r == 0.0) {
+        double const sr = std::copysign(r, pp);
+        double const sum = pp + sr, diff = pp - sr;
+        double const wbig = shift + sum;
+        double wsmall = shift + diff;
+        if (0.5 * std::fabs(wbig) > mx(std::fabs(wsmall), safmin)) {
+            double const wdet = (a11 * a22 - a12 * a21) * (binv11 * binv22);
+            wsmall = wdet / wbig;
+        }
+        if (pp > abi22) { wr1 = mn(wbig, wsmall); wr2 = mx(wbig, wsmall); }
+        else { wr1 = mx(wbig, wsmall); wr2 = mn(wbig, wsmall); }
+        wi = 0.0;
+    } else {
+        wr1 = shift + pp; wr2 = wr1; wi = r;
+    }
+    double const c1 = bsize * (safmin * mx(1.0, ascale));
+    double const c2 = safmin * mx(1.0, bnorm);
+    double const c3 = bsize * safmin;
+    double const c4 = (ascale <= 1.0 && bsize <= 1.0) ? mn(1.0, (ascale / safmin) * bsize) : 1.0;
+    double const c5 = (ascale <= 1.0 || bsize <= 1.0) ? mn(1.0, ascale * bsize) : 1.0;
+    double wabs = std::fabs(wr1) + std::fabs(wi);
+    double wsize = mx(mx(safmin, c1), mx(fuzzy1 * (wabs * c2 + c3), mn(c4, 0.5 * mx(wabs, c5))));
+    if (wsize != 1.0) {
+        double const wscale = 1.0 / wsize;
+        if (wsize > 1.0) scale1 = (mx(ascale, bsize) * wscale) * mn(ascale, bsize);
+        else scale1 = (mn(ascale, bsize) * wscale) * mx(ascale, bsize);
+        wr1 *= wscale;
+        if (wi != 0.0) { wi *= wscale; wr2 = wr1; scale2 = scale1; }
+    } else {
+        scale1 = ascale * bsize;
+        scale2 = scale1;
+    }
+    if (wi == 0.0) {
+        wabs = std::fabs(wr2);
+        wsize = mx(mx(safmin, c1), mx(fuzzy1 * (wabs * c2 + c3), mn(c4, 0.5 * mx(wabs, c5))));
+        if (wsize != 1.0) {
+            double const wscale = 1.0 / wsize;
+            if (wsize > 1.0) scale2 = (mx(ascale, bsize) * wscale) * mn(ascale, bsize);
+            else scale2 = (mn(ascale, bsize) * wscale) * mx(ascale, bsize);
+            wr2 *= wscale;
+        } else scale2 = ascale * bsize;
+    }
+}
+
 } // namespace
 
 // Standardises the 2x2 diagonal block at p of the pencil (A,B) (B upper triangular):
@@ -387,20 +488,19 @@ void gep_push_inf_down_window(int w, double *A_, int lda, double *B_, int ldb, d
     }
 }
 
+// The eigenvalues (alpha_r, alpha_i, beta) of a generalized Schur form in diagonal order, as the reference
+// returns them (common/tasks.c:1120-1150, schur/cpu_utils.c:3493-3520): (S(i,i), 0, T(i,i)) for a 1 x 1
+// block, dlag2's (wr, +-wi, scale) for a 2 x 2 block.
 void gep_extract_eigenvalues(int n, const double *S_, int lds, const double *T_, int ldt,
     double *ar, double *ai, double *be)
 {
     Mat S{const_cast<double *>(S_), lds}, T{const_cast<double *>(T_), ldt};
     for (int i = 0; i < n; i++) {
         if (i + 1 < n && S(i + 1, i) != 0.0) {
-            double lr[2];
-            if (pencil2_eigenvalues(S(i, i), S(i, i + 1), S(i + 1, i), S(i + 1, i + 1),
-                    T(i, i), T(i, i + 1), T(i + 1, i + 1), lr)) {
-                // (a block that the standardisation could not split although its eigenvalues are
-                // real -- they differ by rounding: report them as they are)
-                ar[i] = lr[0]; ar[i + 1] = lr[1]; ai[i] = ai[i + 1] = 0.0;
-            } else { ar[i] = ar[i + 1] = lr[0]; ai[i] = lr[1]; ai[i + 1] = -lr[1]; }
-            be[i] = be[i + 1] = 1.0;
+            double s1, s2, w1, w2, wi;
+            pencil2_dlag2(&S(i, i), lds, &T(i, i), ldt, s1, s2, w1, w2, wi);
+            ar[i] = w1; ai[i] = wi; be[i] = s1;
+            ar[i + 1] = w2; ai[i + 1] = -wi; be[i + 1] = s2;
             i++;
         } else { ar[i] = S(i, i); ai[i] = 0.0; be[i] = T(i, i); }
     }
@@ -884,6 +984,10 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
 #ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
+__attribute__((visibility("default")))
+void sn_internal_gep_extract_eigenvalues(int n, double const *S, int lds, double const *T, int ldt,
+    double *ar, double *ai, double *be)
+{ sn::host::gep_extract_eigenvalues(n, S, lds, T, ldt, ar, ai, be); }
 __attribute__((visibility("default")))
 void sn_internal_gep_push_inf_down_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int from, int deflate)

@@ -13,6 +13,8 @@ struct Tuning {
     long hess_cache_mb = 256;       // SN_HESS_CACHE_MB: trailing matrices below this size are read with temporal loads
     int hess_side_cus = 0;          // SN_HESS_SIDE_CUS: CU mask of the side stream (0 = none)
     bool hess_noside = false;       // SN_HESS_NOSIDE: delayed updates on the critical stream
+    int hess_fold = 0;              // SN_HESS_FOLD: fold of the sharded gemv's partials (0 release/acquire ticket, 1 sc1 only, 2 own launch)
+    int team_fail_rank = -1;        // SN_TEAM_FAIL_RANK: this rank of the one-process team reports "no memory" (tests of the error path)
     // Schur
     bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
     int schur_lazy_batch = 32;      // SN_SCHUR_LAZY_BATCH

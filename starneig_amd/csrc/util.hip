@@ -22,6 +22,8 @@ Tuning const &tuning()
         t.hess_max_panels = geti("SN_HESS_MAX_PANELS", t.hess_max_panels);
         t.hess_cache_mb = geti("SN_HESS_CACHE_MB", (int)t.hess_cache_mb);
         t.hess_noside = getb("SN_HESS_NOSIDE");
+        t.hess_fold = geti("SN_HESS_FOLD", t.hess_fold);
+        t.team_fail_rank = geti("SN_TEAM_FAIL_RANK", t.team_fail_rank);
         t.hess_side_cus = geti("SN_HESS_SIDE_CUS", 0);
         t.schur_nolazyrows = getb("SN_SCHUR_NOLAZYROWS");
         t.schur_lazy_batch = geti("SN_SCHUR_LAZY_BATCH", t.schur_lazy_batch);

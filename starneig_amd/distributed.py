@@ -138,9 +138,11 @@ class Collectives:
             os._exit(3)
 
 
-def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
+def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None, sample_every=0):
     """Reduces the matrix held (identically) by every rank in tA; on return every rank holds
-    the full Hessenberg form in tA and the full Q in tQ.  Returns (rc, stats)."""
+    the full Hessenberg form in tA and the full Q in tQ.  Returns (rc, stats).
+    sample_every = k > 0: every k-th gemv launch of this rank's shard (with the all-reduce behind it)
+    and every per-panel collective is timed with HIP events on the reduction's stream (bench.py)."""
     import torch
     import torch.distributed as dist
     L = lib.load()
@@ -155,7 +157,8 @@ def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
     coll = Collectives({0: tY, 1: tP, 2: tW, 3: tA.view(-1),
                         4: tQ.view(-1) if tQ is not None else None}, group)
     native = native_rccl(group)
-    st = (C.c_double * 8)()
+    st = (C.c_double * 32)()
+    st[7] = float(max(0, sample_every))
     rc = L.starneig_amd_hessenberg_sharded_device(
         n, pw, tA.data_ptr(), tA.shape[1], tQ.data_ptr() if tQ is not None else None,
         tQ.shape[1] if tQ is not None else 0, tY.data_ptr(), tP.data_ptr(), tW.data_ptr(),
@@ -165,6 +168,12 @@ def hessenberg_sharded(tA, tQ, n=None, panel_width=-1, group=None):
         None, torch.cuda.current_stream().cuda_stream, st)
     stats = {"total_ms": st[0], "gemv_bytes": st[1], "gemm_flops": st[2],
              "gemv_launches": int(st[5]), "collectives": "RCCL, called from the library" if native else dict(coll.calls)}
+    if sample_every > 0:
+        kinds = ("allreduce_y", "broadcast_panel", "allreduce_w", "assembly")
+        stats.update({"gemv_sampled_ms": st[8], "gemv_sampled_bytes": st[9], "gemv_sampled_launches": int(st[10]),
+                      "allreduce_y_calls": int(st[11]), "rccl_ranks": int(st[24]) if native else 0,
+                      "comm": {k: {"ms": st[12 + 3 * i], "bytes": st[13 + 3 * i], "calls": int(st[14 + 3 * i])}
+                               for i, k in enumerate(kinds)}})
     return rc, stats
 
 

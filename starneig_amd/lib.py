@@ -165,8 +165,27 @@ def load():
 
 # ---- life cycle (reference node.h:178-220) --------------------------------------
 
-def node_init(cores=USE_ALL, gpus=USE_ALL, flags=DEFAULT):
+_atexit_registered = [False]
+
+
+def node_init(cores=USE_ALL, gpus=1, flags=DEFAULT):
+    """starneig_node_init.  `gpus` defaults to ONE device here (the C interface takes what the caller
+    passes, STARNEIG_USE_ALL included): in the one-process-per-GPU mode of distributed.py every rank owns
+    one device, and a default of "all" would make every rank start a team on every device of the node.
+    Several devices from one process are an explicit request: node_init(cores, gpus=N)."""
     load().starneig_node_init(cores, gpus, flags)
+    if not _atexit_registered[0]:
+        import atexit
+        atexit.register(_finalize_at_exit)
+        _atexit_registered[0] = True
+
+
+def _finalize_at_exit():
+    try:
+        if _lib is not None and _lib.starneig_node_initialized():
+            _lib.starneig_node_finalize()
+    except Exception:
+        pass
 
 
 def node_initialized():

@@ -205,3 +205,29 @@ def test_close_real_pair_is_split_and_reported_accurately():
     ref = np.sort(sl.eigvals(A0, B0).real)
     assert np.abs(np.sort(ar / be) - ref).max() <= 100 * U * np.abs(ref).max()
     check_gschur(A0, B0, A, B, Q, Z, tol=50)
+
+
+def test_returned_eigenvalues_of_2x2_blocks_are_dlag2_bit_for_bit():
+    """The product returns (alpha, beta) of a 2 x 2 block as LAPACK dlag2's (wr, +-wi, scale), like the
+    reference (common/math.c:148-176) -- the same bits as LAPACK itself and as the oracle's extraction, so
+    that the reference's `eigenvalues` hook holds at its own thresholds (10^3 / 10^4 u, hooks.c:787-788)
+    even on blocks whose discriminant nearly vanishes."""
+    import os
+    import oracle as O
+    hooks = S.lib.load_test_hooks()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dlag2_cases.npz"))
+    dp = C.POINTER(C.c_double)
+    checked = 0
+    for A, B, want in zip(g["A"], g["B"], g["out"]):
+        if A[1, 0] == 0.0:
+            continue
+        a, b = np.asfortranarray(A), np.asfortranarray(B)
+        ar, ai, be = np.zeros(2), np.zeros(2), np.zeros(2)
+        hooks.sn_internal_gep_extract_eigenvalues(2, a.ctypes.data_as(dp), 2, b.ctypes.data_as(dp), 2,
+                                                  ar.ctypes.data_as(dp), ai.ctypes.data_as(dp), be.ctypes.data_as(dp))
+        s1, s2, w1, w2, wi = want
+        assert (ar[0], ar[1], ai[0], ai[1], be[0], be[1]) == (w1, w2, wi, -wi, s1, s2)
+        oar, oai, obe = O.gep_extract_eigenvalues(a, b)
+        assert np.array_equal(oar, ar) and np.array_equal(oai, ai) and np.array_equal(obe, be)
+        checked += 1
+    assert checked > 800
