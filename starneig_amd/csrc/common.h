@@ -85,6 +85,21 @@ struct HessenbergTimings {
 int hessenberg_device(hipStream_t s, int n, int begin, int end, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ, HessenbergTimings *timings);
 
+// Device-side exchange of the per-column partial vectors y = A_r v between the ranks of a one-process team
+// (node_team.hip): rank r's gemv launch writes its folded row tiles into slot r of EVERY rank's buffer (peer
+// stores: the same device, or peers over xGMI) and raises a flag per tile; the next column kernel of each rank
+// waits for the flags of the tiles it reads and sums the world slots in rank order -- no host round trip, no
+// collective launch, the same bits on every rank.  Passed to the kernels by value.
+constexpr int HESS_MAX_RANKS = 16;
+constexpr int HESS_MAX_ROW_TILES = 256;     // row tiles of a gemv launch (512 rows each): n <= 131072
+struct HessExchange {
+    double *slots[HESS_MAX_RANKS];  // slots[r]: rank r's buffer, [2 parities][world][ldp] doubles
+    int *flags[HESS_MAX_RANKS];     // flags[r]: rank r's flags, [world][HESS_MAX_ROW_TILES]: last sequence number published
+    int *error;                     // this rank's error word (a wait that timed out)
+    int world, rank;
+    int seq_base;                   // sequence number of the last column of the previous reduction
+};
+
 // Collective callbacks of the sharded reduction.  buffer ids: 0 = y vector, 1 = panel P,
 // 2 = W scratch, 3 = A, 4 = Q (all allocated by the caller, who maps the id to its handle).
 struct HessComm {
@@ -92,6 +107,7 @@ struct HessComm {
     void (*allreduce_sum)(void *ctx, int buffer, long offset, long count);
     void (*broadcast)(void *ctx, int buffer, long offset, long count, int root);
     void *ctx;
+    HessExchange const *exchange = nullptr;     // non-null: the per-column all-reduce of y runs on the device (above)
 };
 int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     double *dA, int ldA, double *dQ, int ldQ,
@@ -143,7 +159,7 @@ void schur_release_workspace();
 // Generalized twin (schur_gep.hip): (dA, dB) Hessenberg-triangular -> generalized Schur form
 int gep_schur_device(hipStream_t s, int n, double *dA, int ldA, double *dB, int ldB,
     double *dQ, int ldQ, double *dZ, int ldZ, double *real, double *imag, double *beta,
-    SchurParams const &params, SchurStats *stats);
+    SchurParams const &params, SchurStats *stats, int level = 0);
 void gep_schur_release_workspace();
 void lcg_pencil(hipStream_t s, int n, unsigned seed, double *H, int ldh, double *R, int ldr);
 // Hessenberg-triangular reduction (hess_tri.hip): general (dA, dB) -> (H, T), dQ <- dQ*U1, dZ <- dZ*U2

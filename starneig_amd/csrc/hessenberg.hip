@@ -159,6 +159,57 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
     }
 }
 
+// ---- device-side exchange of the sharded gemv's result (HessExchange, common.h) ------------------------------
+// Consumer side: the rows [g_lo, g_hi] of this workgroup lie in at most two row tiles of the gemv launch;
+// 2 * world lanes poll the flags (system-scope relaxed loads; bounded: a rank that died must not hang the
+// others), one acquire for the workgroup, then every row sums the world slots in rank order.
+__device__ __forceinline__ void exchange_wait(HessExchange const &x, int seq, int tile_lo, int tile_hi)
+{
+    int const tid = threadIdx.x;
+    if (tid < 2 * x.world) {
+        int const r = tid >> 1, tile = (tid & 1) ? tile_hi : tile_lo;
+        int const *f = x.flags[x.rank] + r * HESS_MAX_ROW_TILES + tile;
+        // (bounded: ~1 s, and once a wait of this rank has timed out the reduction is lost anyway -- the rest of
+        // it does not wait at all, the host reports the failure)
+        long spins = 0;
+        bool const lost = __hip_atomic_load(x.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        while (!lost && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 22)) { __hip_atomic_store(x.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double exchange_sum(HessExchange const &x, int seq, int ldp, int g)
+{
+    double const *base = x.slots[x.rank] + (size_t)(seq & 1) * x.world * ldp + g;
+    double s = __hip_atomic_load(base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < x.world; r++)
+        s += __hip_atomic_load(base + (size_t)r * ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return s;
+}
+// a rank that owns no column block right of the pivot publishes zeros (one workgroup per row tile)
+__global__ __launch_bounds__(256)
+void hess_exchange_zero_kernel(HessExchange x, int seq, int R0, int E, int ldp)
+{
+    int const tile = blockIdx.x, g = (R0 & ~15) + tile * 512 + threadIdx.x * 2;
+    for (int r = 0; r < x.world; r++) {
+        double *dst = x.slots[r] + ((size_t)(seq & 1) * x.world + x.rank) * ldp;
+        if (g >= R0 && g < E) __hip_atomic_store(dst + g, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (g + 1 >= R0 && g + 1 < E) __hip_atomic_store(dst + g + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = 0; r < x.world; r++)
+            __hip_atomic_store(x.flags[r] + x.rank * HESS_MAX_ROW_TILES + tile, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // colA(j), j >= 1.  The two products with the OLD columns of Y that this step needs,
 //   t1 = Y(:,0:j-1) w_v   (for Y(:,j-1) = tau (y - t1), cpu.c:267-270)  and
 //   t2 = Y(:,0:j-1) V(piv-1,0:j-1)^T   (for p' = P(:,j) - Y V(piv-1,:)^T, cpu.c:98-99),
@@ -169,7 +220,8 @@ __global__ __launch_bounds__(CT)
 void hess_colA_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ VT,
     double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
-    double const *__restrict__ t12, double *__restrict__ acc, double const *__restrict__ scal)
+    double const *__restrict__ t12, double *__restrict__ acc, double const *__restrict__ scal,
+    HessExchange x = HessExchange{}, int seq = 0)
 {
     __shared__ double s_p[RB], s_scal[3];
     int const tid = threadIdx.x;
@@ -180,9 +232,14 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     // scalars of column j-1 as published by gemv(j-1): P(piv-1, j-1) itself is overwritten
     // with beta by one block of THIS launch, so it must not be re-read here
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
+    if (x.world) {
+        int const base = R0 & ~15;
+        exchange_wait(x, seq, (g0 - base) / GEMV_ROWS, (min(g0 + RB, E) - 1 - base) / GEMV_ROWS);
+    }
     double ysum = 0.0, pj = 0.0, t1 = 0.0, t2 = 0.0;
     if (h == 0 && g < E) {
-        ysum = split_sum(ypart, ldp, g, nsplit); pj = P[(size_t)j * ldp + g];
+        ysum = x.world ? exchange_sum(x, seq, ldp, g) : split_sum(ypart, ldp, g, nsplit);
+        pj = P[(size_t)j * ldp + g];
         t1 = t12[g]; t2 = t12[ldp + g];
     }
     __syncthreads();
@@ -211,7 +268,7 @@ __global__ __launch_bounds__(CT)
 void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double *__restrict__ Y,
     double const *__restrict__ ypart, int nsplit, double const *__restrict__ acc,
-    double const *__restrict__ scal)
+    double const *__restrict__ scal, HessExchange x = HessExchange{}, int seq = 0)
 {
     __shared__ double s_wv[MAXJ], s_y[NG - 1][RB], s_scal[3];
     int const tid = threadIdx.x;
@@ -219,6 +276,10 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     int const g = R0 + blockIdx.x * RB + r;
     int const pivprev = R0 + j - 1, parp = (j - 1) & 1;
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
+    if (x.world) {
+        int const base = R0 & ~15, g0 = R0 + blockIdx.x * RB;
+        exchange_wait(x, seq, (g0 - base) / GEMV_ROWS, (min(g0 + RB, E) - 1 - base) / GEMV_ROWS);
+    }
     __syncthreads();
     for (int l = tid; l < j - 1; l += CT)
         s_wv[l] = V[(size_t)l * ldp + pivprev]
@@ -233,7 +294,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
         double const tau = s_scal[1], beta = s_scal[2];
         #pragma unroll
         for (int q = 0; q < NG - 1; q++) yacc += s_y[q][r];
-        double ysum = split_sum(ypart, ldp, g, nsplit);
+        double ysum = x.world ? exchange_sum(x, seq, ldp, g) : split_sum(ypart, ldp, g, nsplit);
         Y[(size_t)(j - 1) * ldp + g] = tau * (ysum - yacc);
         if (g == pivprev) P[(size_t)(j - 1) * ldp + g] = beta;
         else if (g > pivprev) P[(size_t)(j - 1) * ldp + g] = 0.0;
@@ -326,7 +387,8 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
     double const *__restrict__ Y, double *__restrict__ t12,
     double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
-    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr, int fold = 0)
+    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr, int fold = 0,
+    HessExchange x = HessExchange{}, int seq = 0)
 {
     __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_t[3][NGS][RBS + 1], s_scal[2];
     __shared__ int s_last;
@@ -488,10 +550,26 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
                         double sum = 0.0;
                         for (int sp = 0; sp < nsplit; sp++)
                             sum += __hip_atomic_load(ypart + (size_t)sp * ldp + gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ysum[gg] = sum;
+                        if (x.world == 0) ysum[gg] = sum;
+                        else    // device-side exchange: this rank's slot on every rank (peer stores)
+                            for (int r = 0; r < x.world; r++)
+                                __hip_atomic_store(x.slots[r] + ((size_t)(seq & 1) * x.world + x.rank) * ldp + gg, sum,
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
                 if (threadIdx.x == 0) __hip_atomic_store(tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x.world) {
+                    // the tile is out on every rank before its flag: drain, workgroup barrier, one release at
+                    // system scope, then the flag stores (Guideline 16, flag form)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (int r = 0; r < x.world; r++)
+                            __hip_atomic_store(x.flags[r] + x.rank * HESS_MAX_ROW_TILES + tile, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
             }
         }
     } else {
@@ -535,7 +613,7 @@ struct HessWorkspace {
     double *S = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
     double *t12 = nullptr;                      // [t1 | t2]: the products with the old columns of Y that colA(j+1) needs, formed in the shadow of gemv(j)
-    static constexpr int MAX_ROW_TILES = 256;   // row tiles of a gemv launch (512 rows each): n <= 131072
+    static constexpr int MAX_ROW_TILES = HESS_MAX_ROW_TILES;    // row tiles of a gemv launch (512 rows each)
     int *tile_cnt = nullptr;                    // sharded gemv: arrivals per row tile (self-resetting)
     hipStream_t side = nullptr, main = nullptr;
     hipEvent_t entry = nullptr;
@@ -895,6 +973,11 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     // each row tile behind an agent-scope release / acquire; 1 the same on sc1 accesses alone (rounds 3-4, kept
     // for the reproducer of tests/test_gpu_node_team.py); 2 by a launch of its own
     int const fold = tuning().hess_fold;
+    // the per-column all-reduce of y on the device (one-process team, common.h HessExchange): column number
+    // `seq` (counted across reductions: the flags are never reset) selects the parity of the slots
+    bool const dev_x = comm.exchange != nullptr && reduce_y && aligned && fold != 2;
+    HessExchange const x = dev_x ? *comm.exchange : HessExchange{};
+    int seq = x.seq_base;
     if (reduce_y && aligned) SN_HIP_CHECK(hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * HessWorkspace::MAX_ROW_TILES, s));
     // measurement (bench.py at N > 1): HIP events on the reduction's stream around every k-th gemv launch
     // and its all-reduce, around the per-panel collectives and the assembly
@@ -953,9 +1036,10 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             double const *ysrc = reduce_y ? dYsum : ws.ypart;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, dP, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.t12, ws.acc, ws.scal);
+                    R0, E, j, ldp, dP, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.t12, ws.acc, ws.scal, x, seq);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
                 R0, E, j, ldp, dP, V, ws.acc);
+            seq++;              // the number of THIS column's gemv
             // owned column blocks that intersect [piv, E): the splits of this rank's share of the gemv
             int const b0 = piv / cb;
             int const first = b0 + ((rank - b0 % world) + world) % world;
@@ -974,7 +1058,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             if (aligned && reduce_y && fold != 2)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, true, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
-                    world, rank, dYsum, ws.tile_cnt, fold);
+                    world, rank, dYsum, ws.tile_cnt, fold, x, seq);
             else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
@@ -983,7 +1067,17 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
                 hipLaunchKernelGGL((hess_gemv_kernel<16, false>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
                     world, rank);
-            if (reduce_y) {
+            if (dev_x) {
+                // nothing to launch: the gemv's last workgroups have written this rank's share to every rank.
+                // (A rank without a column block right of the pivot publishes zeros.)
+                if (nsplit == 0)
+                    hipLaunchKernelGGL(hess_exchange_zero_kernel, dim3(row_tiles), dim3(256), 0, s, x, seq, R0, E, ldp);
+                if (sampled) {
+                    SN_HIP_CHECK(hipEventRecord(ws.sample_ev[2 * nsampled + 1], s));
+                    ws.sample_bytes.push_back(8.0 * (double)m * own_cols); nsampled++;
+                }
+                allreduce_y_calls++;
+            } else if (reduce_y) {
                 if (nsplit == 0) SN_HIP_CHECK(hipMemsetAsync(dYsum + R0, 0, (size_t)m * sizeof(double), s));
                 else if (!aligned || fold == 2)
                     hipLaunchKernelGGL(hess_ysum_kernel, dim3(divceil(m, 256)), dim3(256), 0, s,
@@ -1004,7 +1098,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             gemv_bytes += 8.0 * (double)m * own_cols;
         }
         hipLaunchKernelGGL(hess_finish_kernel, dim3(nwg), dim3(CT), 0, s,
-            R0, E, nb, ldp, dP, V, Ys, reduce_y ? dYsum : ws.ypart, reduce_y ? 1 : nsplit, ws.acc, ws.scal);
+            R0, E, nb, ldp, dP, V, Ys, reduce_y ? dYsum : ws.ypart, reduce_y ? 1 : nsplit, ws.acc, ws.scal, x, seq);
 
         // fused trailing update (hessenberg_device) on every run of adjacent owned blocks right of the panel
         // (one run when this rank owns everything; single blocks otherwise):

@@ -112,11 +112,34 @@ struct Team {
     double *tmp[MAX_RANKS] = {};
     long tmp_cap[MAX_RANKS] = {};
     hipStream_t stream[MAX_RANKS] = {};
+    // device-side exchange of the per-column vectors of the sharded Hessenberg reduction (common.h HessExchange):
+    // per rank a flag array for the life of the team, a slot buffer per call, an error word
+    bool device_exchange = false;
+    int *xflags[MAX_RANKS] = {};
+    double *xslots[MAX_RANKS] = {};
+    long xslots_cap[MAX_RANKS] = {};
+    int seq_base = 0;               // columns exchanged so far (the same on every rank)
 
     void worker(int rank)
     {
         SN_HIP_CHECK(hipSetDevice(device[rank]));
-        SN_HIP_CHECK(hipStreamCreateWithFlags(&stream[rank], hipStreamNonBlocking));
+        {
+            // The rank's stream gets a hardware queue of its OWN (a stream created with a CU mask never shares one;
+            // util.hip make_stream): with the device-side exchange a column kernel of this rank waits, spinning, for
+            // the gemv launch of another rank -- if the runtime had put both streams on one hardware queue (it
+            // multiplexes the plain streams of a priority level onto four), that launch would sit BEHIND the
+            // kernel that waits for it.  Only ranks that share a device can meet in one queue; the others keep
+            // a plain stream.
+            bool shared = false;
+            for (int r = 0; r < world; r++) if (r != rank && device[r] == device[rank]) shared = true;
+            hipDeviceProp_t prop;
+            if (shared && !tuning().team_pooled_stream && hipGetDeviceProperties(&prop, device[rank]) == hipSuccess) {
+                int const words = (prop.multiProcessorCount + 31) / 32;
+                std::vector<uint32_t> mask(words, 0xffffffffu);
+                if (hipExtStreamCreateWithCUMask(&stream[rank], words, mask.data()) != hipSuccess) { (void)hipGetLastError(); stream[rank] = nullptr; }
+            }
+            if (!stream[rank]) SN_HIP_CHECK(hipStreamCreateWithFlags(&stream[rank], hipStreamNonBlocking));
+        }
         unsigned seen = 0;
         for (;;) {
             std::function<void(int)> f;
@@ -139,7 +162,9 @@ struct Team {
         staging_release();
         rccl_finalize();
         if (tmp[rank]) { SN_HIP_CHECK(hipFree(tmp[rank])); tmp[rank] = nullptr; tmp_cap[rank] = 0; }
-        SN_HIP_CHECK(hipStreamDestroy(stream[rank]));
+        if (xflags[rank]) { SN_HIP_CHECK(hipFree(xflags[rank])); xflags[rank] = nullptr; }
+        if (xslots[rank]) { SN_HIP_CHECK(hipFree(xslots[rank])); xslots[rank] = nullptr; xslots_cap[rank] = 0; }
+        SN_HIP_CHECK(hipStreamDestroy(stream[rank])); stream[rank] = nullptr;
     }
     void run(std::function<void(int)> f)
     {
@@ -153,6 +178,9 @@ struct Team {
         world = (int)devs.size(); device = devs; bar.n = world; quit = false;
         job_gen = 0; job = nullptr; done = 0;       // (no worker is alive here: the new ones start level with the counter)
         for (int r = 0; r < world; r++) th.emplace_back([this, r] { worker(r); });
+        // every worker has created its stream (= its hardware queue) before the first real job starts: creating
+        // a queue makes the driver unmap and remap the process' run list, i.e. preempts the waves in flight
+        run([](int) {});
         // distinct devices: RCCL if it loads and every rank gets its communicator
         bool distinct = true;
         for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (devs[a] == devs[b]) distinct = false;
@@ -182,7 +210,47 @@ struct Team {
             if (unreachable.load() > 0) {
                 fprintf(stderr, "[starneig-amd] no RCCL and no peer access between the devices: the calls stay on one GPU\n");
                 stop();
+                return;
             }
+        }
+        // Per-column exchange of the sharded Hessenberg reduction ON THE DEVICE (peer stores + flags, no host round
+        // trip, hessenberg.hip exchange_wait): the default where the ranks sit on distinct devices without RCCL;
+        // with RCCL the collectives stay RCCL's unless STARNEIG_AMD_TEAM_EXCHANGE=device asks for the peer-store
+        // path over xGMI (it has run on virtual ranks only).  Ranks that SHARE a device (the virtual ranks of the
+        // one-GPU test box) keep the host exchange by default: there a column kernel that spins for another
+        // rank's gemv takes issue slots from the very launch it waits for (measured, n = 8000, 2 / 4 virtual
+        // ranks: 1.34 / 1.67 s on the device against 1.04 / 1.33 s through the host).
+        // =host / =device force either.
+        char const *mode = getenv("STARNEIG_AMD_TEAM_EXCHANGE");
+        device_exchange = world > 1 && (mode ? strcmp(mode, "device") == 0 : (distinct && !use_rccl));
+        if (device_exchange && use_rccl && distinct) {
+            // peer stores need peer access, which the RCCL branch above did not set up
+            std::atomic<int> unreachable{0};
+            run([&](int rank) {
+                for (int r = 0; r < world; r++) {
+                    if (r == rank) continue;
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, device[rank], device[r]) != hipSuccess || !can) { unreachable++; continue; }
+                    hipError_t const e = hipDeviceEnablePeerAccess(device[r], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) unreachable++;
+                    (void)hipGetLastError();
+                }
+            });
+            if (unreachable.load() > 0) device_exchange = false;
+        }
+        if (device_exchange) {
+            std::atomic<int> failed{0};
+            run([&](int rank) {
+                size_t const bytes = (size_t)MAX_RANKS * HESS_MAX_ROW_TILES * sizeof(int) + 64;
+                // fine-grained: written by peers, polled by this device's kernels
+                if (hipExtMallocWithFlags((void **)&xflags[rank], bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (hipMalloc((void **)&xflags[rank], bytes) != hipSuccess) { (void)hipGetLastError(); xflags[rank] = nullptr; failed++; return; }
+                }
+                SN_HIP_CHECK(hipMemset(xflags[rank], 0, bytes));
+            });
+            if (failed.load() > 0) device_exchange = false;
+            seq_base = 0;
         }
     }
     void stop()
@@ -193,7 +261,29 @@ struct Team {
         th.clear(); world = 0;
     }
 
-    // ---- collectives of one rank (called from its thread, same order on every rank) ----------
+    // debugging aid (STARNEIG_AMD_TUNING=1 SN_TEAM_VERIFY=1): after every in-process collective every rank hashes
+    // its copy of the buffer on the host and the ranks compare -- a collective that delivered different bits to
+    // different ranks is reported with its ordinal
+    unsigned long long vhash[MAX_RANKS] = {};
+    long vcount = 0;
+    void verify(int rank, char const *what, double const *buf, long count, hipStream_t s)
+    {
+        if (!tuning().team_verify) return;
+        std::vector<unsigned long long> h((size_t)count);
+        SN_HIP_CHECK(hipMemcpyAsync(h.data(), buf, (size_t)count * 8, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        unsigned long long x = 1469598103934665603ull;
+        for (long i = 0; i < count; i++) { x ^= h[(size_t)i]; x *= 1099511628211ull; }
+        vhash[rank] = x;
+        bar.wait();
+        if (rank == 0) {
+            vcount++;
+            for (int r = 1; r < world; r++)
+                if (vhash[r] != vhash[0])
+                    fprintf(stderr, "[starneig-amd] team verify: %s #%ld (%ld doubles): rank %d differs from rank 0\n", what, vcount, count, r);
+        }
+        bar.wait();
+    }
     void allreduce(int rank, double *buf, long count, hipStream_t s)
     {
         if (use_rccl) { if (rccl_allreduce_sum(buf, count, s) != 0) abort(); return; }
@@ -211,6 +301,7 @@ struct Team {
         SN_HIP_CHECK(hipStreamSynchronize(s));
         bar.wait();                                     // everybody has read everybody's buffer
         SN_HIP_CHECK(hipMemcpyAsync(buf, tmp[rank], (size_t)count * 8, hipMemcpyDeviceToDevice, s));
+        verify(rank, "all-reduce", buf, count, s);
     }
     void broadcast(int rank, double *buf, long count, int root, hipStream_t s)
     {
@@ -223,6 +314,7 @@ struct Team {
             SN_HIP_CHECK(hipStreamSynchronize(s));
         }
         bar.wait();                                     // the root may overwrite its buffer again
+        verify(rank, "broadcast", buf, count, s);
     }
 };
 
@@ -297,11 +389,42 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
         T.bar.wait();                                   // nobody writes into A / Q before everybody has read them
         RankComm rc{&T, rank, {dY, dP, dW, dA, dQ}, s};
         HessComm comm{rank, world, team_allreduce_cb, team_broadcast_cb, &rc};
-        int const r = hessenberg_sharded_device(s, n, panel_width, dA, ld, dQ, ld, dY, dP, dW,
-            (long)n * panel_width, comm, nullptr);
+        HessExchange ex{};
+        if (T.device_exchange) {
+            long const need = 2L * world * ldp;
+            if (T.xslots_cap[rank] < need) {
+                if (T.xslots[rank]) SN_HIP_CHECK(hipFree(T.xslots[rank]));
+                T.xslots[rank] = nullptr; T.xslots_cap[rank] = 0;
+                if (hipExtMallocWithFlags((void **)&T.xslots[rank], (size_t)need * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+                    (void)hipGetLastError();
+                    SN_TEAM_TRY(hipMalloc((void **)&T.xslots[rank], (size_t)need * 8), failures);
+                }
+                if (T.xslots[rank]) T.xslots_cap[rank] = need;
+            }
+            T.bar.wait();                               // every rank's slot buffer exists (or the call fails as a whole)
+            if (failures.load() == 0) {
+                for (int r2 = 0; r2 < world; r2++) { ex.slots[r2] = T.xslots[r2]; ex.flags[r2] = T.xflags[r2]; }
+                ex.error = T.xflags[rank] + MAX_RANKS * HESS_MAX_ROW_TILES;    // the word behind this rank's flags
+                ex.world = world; ex.rank = rank; ex.seq_base = T.seq_base;
+                comm.exchange = &ex;
+            }
+        }
+        int r = failures.load() == 0 ? hessenberg_sharded_device(s, n, panel_width, dA, ld, dQ, ld, dY, dP, dW,
+            (long)n * panel_width, comm, nullptr) : -1;
         SN_HIP_CHECK(hipStreamSynchronize(s));
+        if (r == 0 && comm.exchange) {
+            int err = 0;
+            SN_HIP_CHECK(hipMemcpy(&err, ex.error, sizeof(int), hipMemcpyDeviceToHost));
+            if (err != 0) {
+                fprintf(stderr, "[starneig-amd] rank %d: a wait of the device-side exchange timed out; the result is not valid\n", rank);
+                SN_HIP_CHECK(hipMemset(ex.error, 0, sizeof(int)));
+                r = -3;
+            }
+        }
         if (r != 0) failures++;
         T.bar.wait();                                   // a failed rank: nobody overwrites the caller's arrays
+        if (failures.load() > 0 && T.device_exchange && T.xflags[rank])    // the exchange starts from scratch next time
+            SN_HIP_CHECK(hipMemset(T.xflags[rank], 0, (size_t)MAX_RANKS * HESS_MAX_ROW_TILES * sizeof(int) + 64));
         if (failures.load() == 0) {
             int const per = divceil(n, world), c0 = std::min(n, rank * per), c1 = std::min(n, c0 + per);
             if (c1 > c0) {
@@ -311,6 +434,7 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
         }
         for (double *p : {dA, dQ, dY, dP, dW}) SN_HIP_CHECK(hipFree(p));
     });
+    if (T.device_exchange) T.seq_base = failures.load() == 0 ? T.seq_base + n - 1 : 0;   // one exchange per reduced column, on every rank
     return failures.load() == 0 ? 0 : 1;
 }
 

@@ -48,7 +48,12 @@ constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BY
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R64 = GemmCfg<64, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_P = UPDATE_LDS_BYTES_L > UPDATE_LDS_BYTES_R ? UPDATE_LDS_BYTES_L : UPDATE_LDS_BYTES_R;
-constexpr int CHASE_LDS_BYTES = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // W, U, two reflector buffers
+constexpr int CHASE_LDS_BYTES_WU = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // rounds 1-4: W and U in LDS, two reflector buffers (150 KB)
+// Round 5: the accumulated factor U lives in REGISTERS (three entries per (bulge, row) pair, handed from bulge
+// to bulge by DPP row shifts, finished columns stored straight to HBM): the window alone is 75 KB, so that a
+// chase workgroup fits on a CU BESIDE one update workgroup (64.5 KB each, two per CU) instead of waiting for an
+// empty CU -- profiles/r4_chase_in_situ.txt: 184 us per launch in situ against 97 us alone.
+constexpr int CHASE_LDS_BYTES = (WS_MAX * LDW + 12 * NB_MAX + 16) * 8;
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
 __device__ __forceinline__ void shift_vector(double const *W, double sr1, double si1,
@@ -114,25 +119,53 @@ __device__ __forceinline__ ChaseReflector chase_build(double *W, int n, int i, i
     return ChaseReflector{v1, v2, tau, j + 1, (tau != 0.0) ? len : 0};
 }
 
-template <int DBG>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
+// one lane's value to the lane below it in its 16-lane DPP row (lane k receives lane k + 1's; the last lane 0)
+__device__ __forceinline__ double dpp_row_shl1(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, true);     // row_shl:1, bound_ctrl
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// the accumulated factor in registers (UREG): one (bulge i, row r) item holds U(r, row0 .. row0 + 2), the
+// three columns of the bulge's current position
+struct UItem {
+    double u0, u1, u2;
+    int r;          // row of U, -1: no item
+};
+
+template <int DBG, bool UREG>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
 __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *W = lds, *U = lds + WS_MAX * LDW, *Rbase = U + WS_MAX * LDW;   // per bulge {v1,v2,tau,-}, two buffers
+    double *W = lds, *U = lds + WS_MAX * LDW, *Rbase = U + (UREG ? 0 : WS_MAX * LDW);   // per bulge {v1,v2,tau,-}, two buffers
     int *Ribase = reinterpret_cast<int *>(Rbase + 8 * NB_MAX);            // per bulge {row0, len}, two buffers
     ChaseTask const t = make_task(step, blockIdx.x);
     int const n = t.n, nb = t.nb, tid = threadIdx.x;
     bool const introduce = t.flags & 1, finalize = t.flags & 2;
+    double *Uo = Uout + (size_t)blockIdx.x * WS_MAX * WS_MAX;
 
     for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         W[c * LDW + r] = H[(size_t)(t.lo + c) * ldH + t.lo + r];
-        U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
+        if (!UREG) U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
     }
     // the (bulge, column) and (bulge, row) pairs a lane owns do not change from step to step
     constexpr int L_ITEMS = (NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
-    constexpr int R_ITEMS = (2 * NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
+    constexpr int R_ITEMS = ((UREG ? 1 : 2) * NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
+    int const rspan = UREG ? n : 2 * n;                                  // items per bulge of the right phase
+    // UREG: lane = bulge i (0..15) + 16 * (row & 3); waves 0..15 hold rows 4w .. 4w + 3, waves 8..15 rows
+    // 32 + 4w .. as well (96 rows = 24 groups of four): the hand-off of an entry from bulge i + 1 to bulge i
+    // is a DPP shift inside a 16-lane row
+    int const ui = tid & 15, usub = (tid >> 4) & 3, uw = tid >> 6;
+    UItem ua{0.0, 0.0, 0.0, -1}, ub{0.0, 0.0, 0.0, -1};
+    if (UREG) {
+        int const ra = 4 * uw + usub, rb = 32 + 4 * uw + usub;
+        if (ui < nb && ra < n) ua.r = ra;
+        if (ui < nb && uw >= 8 && rb < n) ub.r = rb;
+    }
     int li[L_ITEMS], lc[L_ITEMS], ri[R_ITEMS], rr_[R_ITEMS];
     #pragma unroll
     for (int k = 0; k < L_ITEMS; k++) {
@@ -142,12 +175,22 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
     #pragma unroll
     for (int k = 0; k < R_ITEMS; k++) {
         int const item = tid + k * CHASE_THREADS;
-        ri[k] = item < nb * n * 2 ? item / (2 * n) : -1; rr_[k] = item - (item / (2 * n)) * 2 * n;
+        ri[k] = item < nb * rspan ? item / rspan : -1; rr_[k] = item - (item / rspan) * rspan;
     }
     __syncthreads();
 
     int const left = introduce ? 2 - 3 * nb : 0;
     int const right = finalize ? n - 2 : t.right;
+    if (UREG) {
+        // U = I: the entries of the bulges' first positions; the columns left of bulge 0's first position are final
+        int const c0 = left + 3 * ui + 1;
+        ua.u0 = (ua.r == c0) ? 1.0 : 0.0; ua.u1 = (ua.r == c0 + 1) ? 1.0 : 0.0; ua.u2 = (ua.r == c0 + 2) ? 1.0 : 0.0;
+        ub.u0 = (ub.r == c0) ? 1.0 : 0.0; ub.u1 = (ub.r == c0 + 1) ? 1.0 : 0.0; ub.u2 = (ub.r == c0 + 2) ? 1.0 : 0.0;
+        for (int idx = tid; idx < (left + 1) * n; idx += CHASE_THREADS) {       // (left + 1 <= 0 at an introduction)
+            int const r = idx % n, c = idx / n;
+            Uo[c * WS_MAX + r] = (r == c) ? 1.0 : 0.0;
+        }
+    }
     ChaseReflector mine{0.0, 0.0, 0.0, 0, 0};
     double sr1 = 0.0, si1 = 0.0, sr2 = 0.0, si2 = 0.0;         // the lane's shift pair (used at introduction)
     if (tid < nb && introduce) {
@@ -218,7 +261,7 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
             if (i < 0 || (DBG & 2)) continue;
             int const row0 = begin + 3 * i + 1;
             int const cs = max(0, min(max(row0, 0), n - 3));            // clamped column for the reads
-            bool const inW = rr < n;
+            bool const inW = UREG || rr < n;
             int const r = inW ? rr : rr - n;
             double *M = inW ? W : U;
             double *p = M + cs * LDW + r;
@@ -233,14 +276,58 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
             q[0] = y0 - sum; q[LDW] = y1 - sum * rf.x;
             if (len == 3) q[2 * LDW] = y2 - sum * rf.y;
         }
+        if (UREG && !(DBG & 2)) {
+            // the accumulated factor: this step's reflector of bulge ui on the three entries each item holds;
+            // then the bulge moves one column on -- its first entry goes to bulge ui - 1 (whose position it
+            // enters; from bulge 0: out to HBM, that column is final), a new one comes from bulge ui + 1 (from
+            // the identity for the leading bulge)
+            d4 const rf = *reinterpret_cast<d4 const *>(R + 4 * min(ui, NB_MAX - 1));
+            int const len = (ui < nb) ? (int)rf.w : 0;
+            int const row0 = begin + 3 * ui + 1;
+            bool const move = begin + 1 < right;
+            #pragma unroll
+            for (int which = 0; which < 2; which++) {
+                UItem &it = which ? ub : ua;
+                if (len != 0 && it.r >= 0) {
+                    double const y2 = (len == 3) ? it.u2 : 0.0;
+                    double const sum = rf.z * (it.u0 + rf.x * it.u1 + rf.y * y2);
+                    it.u0 -= sum; it.u1 -= sum * rf.x;
+                    if (len == 3) it.u2 -= sum * rf.y;
+                }
+                if (move) {     // (uniform: every lane of the wave takes part in the shift)
+                    double const leaving = it.u0;
+                    double incoming = dpp_row_shl1(leaving);
+                    if (ui == nb - 1) incoming = (it.r == row0 + 3) ? 1.0 : 0.0;
+                    if (ui == 0 && it.r >= 0 && row0 >= 0 && row0 < n) Uo[row0 * WS_MAX + it.r] = leaving;
+                    it.u0 = it.u1; it.u1 = it.u2; it.u2 = incoming;
+                }
+            }
+        }
         __syncthreads();
     }
 
-    double *Uo = Uout + (size_t)blockIdx.x * WS_MAX * WS_MAX;
     for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         H[(size_t)(t.lo + c) * ldH + t.lo + r] = W[c * LDW + r];
-        Uo[c * WS_MAX + r] = U[c * LDW + r];
+        if (!UREG) Uo[c * WS_MAX + r] = U[c * LDW + r];
+    }
+    if (UREG) {
+        // what the items still hold (the bulges' last positions), and the identity right of the leading bulge
+        int const last = max(left, right - 1);                 // `begin` of the last step (no step: the first positions)
+        int const c0 = last + 3 * ui + 1;
+        #pragma unroll
+        for (int which = 0; which < 2; which++) {
+            UItem const &it = which ? ub : ua;
+            if (it.r < 0) continue;
+            if (c0 >= 0 && c0 < n) Uo[c0 * WS_MAX + it.r] = it.u0;
+            if (c0 + 1 >= 0 && c0 + 1 < n) Uo[(c0 + 1) * WS_MAX + it.r] = it.u1;
+            if (c0 + 2 >= 0 && c0 + 2 < n) Uo[(c0 + 2) * WS_MAX + it.r] = it.u2;
+        }
+        int const cfirst = max(0, last + 3 * nb + 1);          // first column no bulge has reached
+        for (int idx = tid; idx < (n - cfirst) * n; idx += CHASE_THREADS) {
+            int const r = idx % n, c = cfirst + idx / n;
+            Uo[c * WS_MAX + r] = (r == c) ? 1.0 : 0.0;
+        }
     }
 }
 
@@ -249,7 +336,15 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
     __builtin_amdgcn_s_setprio(3);      // the latency-bound chain outranks the update kernels in instruction issue
-    schur_chase_body<0>(step, H, ldH, Uout, sr, si);
+    schur_chase_body<0, true>(step, H, ldH, Uout, sr, si);
+}
+// rounds 1-4: the accumulated factor in LDS beside the window (SN_SCHUR_CHASE_ULDS=1: comparisons, chase_bench.py)
+__global__ __launch_bounds__(CHASE_THREADS)
+void schur_chase_ulds_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
+{
+    __builtin_amdgcn_s_setprio(3);
+    schur_chase_body<0, false>(step, H, ldH, Uout, sr, si);
 }
 #ifdef SN_TEST_HOOKS
 template <int DBG>
@@ -257,7 +352,7 @@ __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
-    schur_chase_body<DBG>(step, H, ldH, Uout, sr, si);
+    schur_chase_body<DBG, false>(step, H, ldH, Uout, sr, si);
 }
 #endif
 
@@ -474,6 +569,8 @@ struct SchurWorkspace {
         if (!attr_set) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_ulds_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES_WU));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
             make_stream(&far, true, hi_prio);
@@ -1056,6 +1153,10 @@ struct Driver {
             // chain's first window would race with the finished chain's pending updates
             // (tests/test_schur_pipeline.py checks this rule on a model of the schedule).
             if (sw.issued > 0 && sw.last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
+            if (tuning().schur_chase_ulds)
+                hipLaunchKernelGGL(schur_chase_ulds_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES_WU, s,
+                    step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
+            else
             hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
                 step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
             sweep_launches++;
@@ -1502,8 +1603,8 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
         SN_HIP_CHECK(hipMemcpy(H, H0, (size_t)ld * n * 8, hipMemcpyDeviceToDevice));
         SN_HIP_CHECK(hipEventRecord(e0, nullptr));
         auto go = [&](auto kern) {
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
-            hipLaunchKernelGGL(kern, dim3(chains), dim3(CHASE_THREADS), CHASE_LDS_BYTES, nullptr, step, H, ld, U, sr, si);
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES_WU));
+            hipLaunchKernelGGL(kern, dim3(chains), dim3(CHASE_THREADS), CHASE_LDS_BYTES_WU, nullptr, step, H, ld, U, sr, si);
         };
         switch (dbg) {
             case 1: go(schur_chase_dbg_kernel<1>); break;
@@ -1511,6 +1612,7 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
             case 3: go(schur_chase_dbg_kernel<3>); break;
             case 4: go(schur_chase_dbg_kernel<4>); break;
             case 7: go(schur_chase_dbg_kernel<7>); break;
+            case 8: go(schur_chase_ulds_kernel); break;
             default: go(schur_chase_kernel);
         }
         SN_HIP_CHECK(hipEventRecord(e1, nullptr));

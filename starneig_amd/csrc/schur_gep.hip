@@ -286,8 +286,9 @@ struct GepWorkspace {
     hipEvent_t q_done[FLUSH_RING] = {};
     long issued_total = 0, flush_total = 0;
     std::vector<long> slot_flush = std::vector<long>(EV_RING, -1);
-    static constexpr int Z_RING = 64;           // AED / small-block factors waiting for the lazy stream
-    double *dQZq = nullptr, *dTmpQ = nullptr;   // Z_RING x {Ql, Zl}; scratch of the lazy stream
+    static constexpr int Z_RING = 64;           // AED / small-block factors waiting for the lazy stream (at most)
+    int z_ring = Z_RING;                        // slots in use: fewer for very large AED windows (2 GB of factors at most)
+    double *dQZq = nullptr, *dTmpQ = nullptr;   // z_ring x {Ql, Zl}; scratch of the lazy stream
     hipEvent_t z_ready[Z_RING] = {}, z_done[Z_RING] = {};
     long z_total = 0;
     hipEvent_t lazy_mark = nullptr;
@@ -308,7 +309,9 @@ struct GepWorkspace {
         ring = std::min(EV_RING, std::max(64, 4 * (n / 30 + 128)));
         std::fill(slot_flush.begin(), slot_flush.end(), -1L);
         SN_HIP_CHECK(hipMalloc((void **)&dU, (size_t)ring * max_chains * 2 * GWS * GWS * 8));
-        SN_HIP_CHECK(hipMalloc((void **)&dQZq, (size_t)Z_RING * 2 * nwmax * nwmax * 8));
+        z_ring = (int)std::max<size_t>(2, std::min<size_t>(Z_RING, ((size_t)2 << 30) / ((size_t)2 * nwmax * nwmax * 8)));
+        z_total = 0;
+        SN_HIP_CHECK(hipMalloc((void **)&dQZq, (size_t)z_ring * 2 * nwmax * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dTmpQ, (size_t)n * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftR, (size_t)8 * nwmax * 8));
         SN_HIP_CHECK(hipMalloc((void **)&dShiftI, (size_t)8 * nwmax * 8));
@@ -352,8 +355,34 @@ struct GepWorkspace {
         }
     }
 };
-static GepWorkspace g_gws;
-void gep_schur_release_workspace() { g_gws.release(); }
+// level 0: the caller's pencil; level 1: the private AED window of a blocked AED (GepDriver::large_aed)
+static GepWorkspace g_gws[2];
+
+// private matrices of a blocked AED: the window pencil, its accumulated factors, the padded pencil whose
+// Hessenberg-triangular reduction restores the form of the undeflated part, local window factors
+struct GepLargeBuffers {
+    int cap = 0, ld = 0;
+    double *dA = nullptr, *dB = nullptr, *dQ = nullptr, *dZ = nullptr;
+    double *dPA = nullptr, *dPB = nullptr, *dPQ = nullptr, *dPZ = nullptr, *dTmp = nullptr;
+    double *dQl = nullptr, *dZl = nullptr;
+    void release() {
+        double **ptrs[] = {&dA, &dB, &dQ, &dZ, &dPA, &dPB, &dPQ, &dPZ, &dTmp, &dQl, &dZl};
+        for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
+        cap = 0;
+    }
+    void ensure(int nw) {
+        if (nw <= cap) return;
+        release();
+        cap = nw; ld = (int)roundup((size_t)nw + 1, 16);
+        size_t const bytes = (size_t)ld * (nw + 1) * 8;
+        double **ptrs[] = {&dA, &dB, &dQ, &dZ, &dPA, &dPB, &dPQ, &dPZ, &dTmp};
+        for (auto p : ptrs) SN_HIP_CHECK(hipMalloc((void **)p, bytes));
+        SN_HIP_CHECK(hipMalloc((void **)&dQl, (size_t)128 * 128 * 8));
+        SN_HIP_CHECK(hipMalloc((void **)&dZl, (size_t)128 * 128 * 8));
+    }
+};
+static GepLargeBuffers g_glarge;
+void gep_schur_release_workspace() { g_gws[0].release(); g_gws[1].release(); g_glarge.release(); }
 
 namespace {
 
@@ -400,9 +429,9 @@ struct GepDriver {
         right_update(A, ldA, lo, lo, w, dZl, ldu);
         right_update(B, ldB, lo, lo, w, dZl, ldu);
         if (Q || Z) {
-            int const slot = (int)(ws.z_total % GepWorkspace::Z_RING);
+            int const slot = (int)(ws.z_total % ws.z_ring);
             double *Qc = ws.dQZq + (size_t)slot * 2 * ws.nwmax * ws.nwmax, *Zc = Qc + (size_t)ws.nwmax * ws.nwmax;
-            if (ws.z_total >= GepWorkspace::Z_RING) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.z_done[slot], 0));
+            if (ws.z_total >= ws.z_ring) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.z_done[slot], 0));
             copy_matrix(s, w, w, dQl, ldu, Qc, w);
             copy_matrix(s, w, w, dZl, ldu, Zc, w);
             SN_HIP_CHECK(hipEventRecord(ws.z_ready[slot], s));
@@ -535,6 +564,186 @@ struct GepDriver {
         return count;
     }
 
+    // ---- blocked AED for windows above aed_parallel_hard_limit (row S5 on the pencil side; reference
+    // schur/core.c:1423-1551 perform_large_aed serves both problems, :1070-1252 perform_deflate_step, :783-1052
+    // perform_deflate_finalize).  The generalized twin of Driver::large_aed in schur.hip: the window pencil is
+    // copied into private matrices and reduced to generalized Schur form RECURSIVELY by this same device path
+    // (level 1: chase kernels, MFMA updates, small host AEDs); the deflation checks run over <= 96-row diagonal
+    // windows from the bottom up (host::gep_deflate_window on pinned copies, the rest of the private pencil and
+    // of its factors sees the swaps as in-place MFMA GEMMs); undeflatable blocks are carried along and flushed
+    // to the top of the AED window in batches (host::gep_reorder_window chains); the spike is embedded as the
+    // first column of a padded pencil whose Hessenberg-triangular reduction (hessenberg_triangular_device)
+    // restores the form of the undeflated part.  Nothing outside the private matrices is touched before the
+    // outcome is known.
+    void large_window_updates(GepLargeBuffers &L, int nw, int wb, int w)
+    {
+        int const ld = L.ld, rc = nw - (wb + w);
+        if (wb > 0) {
+            dgemm_right_inplace(s, wb, w, L.dZl, w, L.dA + (size_t)wb * ld, ld);
+            dgemm_right_inplace(s, wb, w, L.dZl, w, L.dB + (size_t)wb * ld, ld);
+        }
+        if (rc > 0) {
+            dgemm_left_inplace(s, w, rc, L.dQl, w, L.dA + (size_t)(wb + w) * ld + wb, ld);
+            dgemm_left_inplace(s, w, rc, L.dQl, w, L.dB + (size_t)(wb + w) * ld + wb, ld);
+        }
+        dgemm_right_inplace(s, nw, w, L.dQl, w, L.dQ + (size_t)wb * ld, ld);
+        dgemm_right_inplace(s, nw, w, L.dZl, w, L.dZ + (size_t)wb * ld, ld);
+        st.gemm_flops += 2.0 * w * w * (2.0 * wb + 2.0 * rc + 2.0 * nw);
+    }
+    void large_window_to_host(GepLargeBuffers &L, int wb, int w, int ldh)
+    {
+        size_t const hp = (size_t)ldh * 8;
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hA, hp, L.dA + (size_t)wb * L.ld + wb, (size_t)L.ld * 8, (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(ws.hB, hp, L.dB + (size_t)wb * L.ld + wb, (size_t)L.ld * 8, (size_t)w * 8, w, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        for (int j = 0; j < w; j++)
+            for (int i = 0; i < w; i++) ws.hQ[(size_t)j * ldh + i] = ws.hZ[(size_t)j * ldh + i] = (i == j) ? 1.0 : 0.0;
+    }
+    void large_window_to_device(GepLargeBuffers &L, int wb, int w, int ldh)
+    {
+        size_t const hp = (size_t)ldh * 8;
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dA + (size_t)wb * L.ld + wb, (size_t)L.ld * 8, ws.hA, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dB + (size_t)wb * L.ld + wb, (size_t)L.ld * 8, ws.hB, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dQl, (size_t)w * 8, ws.hQ, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+        SN_HIP_CHECK(hipMemcpy2DAsync(L.dZl, (size_t)w * 8, ws.hZ, hp, (size_t)w * 8, w, hipMemcpyHostToDevice, s));
+    }
+
+    double prof_laed[4] = {0, 0, 0, 0}; int prof_laed_calls = 0, prof_laed_windows = 0;
+    host::AedResult large_aed(int kw, int nw, double sub, double thres, SchurParams const &prm,
+        double *spike, double *sr, double *si)
+    {
+        host::AedResult res{0, 0, 0};
+        double const tl0 = wall(); prof_laed_calls++;
+        GepLargeBuffers &L = g_glarge;
+        L.ensure(nw);
+        int const ld = L.ld;
+        constexpr int WD = 128;                 // reorder window (in-place update tiles)
+        constexpr int WDD = 96;                 // deflation window: its undeflatable blocks must fit a reorder window with room to move
+        copy_matrix(s, nw, nw, A + (size_t)kw * ldA + kw, ldA, L.dA, ld);
+        copy_matrix(s, nw, nw, B + (size_t)kw * ldB + kw, ldB, L.dB, ld);
+        set_matrix(s, nw, nw, 0.0, 1.0, L.dQ, ld);
+        set_matrix(s, nw, nw, 0.0, 1.0, L.dZ, ld);
+        // (1) generalized Schur form of the window, recursively on the device (default small AED windows)
+        std::vector<double> war(nw), wai(nw), wbe(nw);
+        SchurParams p1;
+        p1.threshold = prm.threshold; p1.threshold_b = prm.threshold_b; p1.threshold_inf = prm.threshold_inf;
+        p1.host_threads = prm.host_threads;
+        int const rc1 = gep_schur_device(s, nw, L.dA, ld, L.dB, ld, L.dQ, ld, L.dZ, ld, war.data(), wai.data(), wbe.data(),
+            p1, nullptr, 1);
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        double const tl1 = wall(); prof_laed[0] += tl1 - tl0;
+        if (rc1 != STARNEIG_SUCCESS) { res.failed = 1; return res; }
+        // (2) the spike sub * Q(0,:) and the block structure
+        std::vector<double> sp(nw), asub(nw, 0.0);
+        SN_HIP_CHECK(hipMemcpy2DAsync(sp.data(), 8, L.dQ, (size_t)ld * 8, 8, nw, hipMemcpyDeviceToHost, s));
+        if (nw > 1)
+            SN_HIP_CHECK(hipMemcpy2DAsync(asub.data(), 8, L.dA + 1, (size_t)(ld + 1) * 8, 8, nw - 1, hipMemcpyDeviceToHost, s));
+        SN_HIP_CHECK(hipStreamSynchronize(s));
+        for (int j = 0; j < nw; j++) sp[j] *= sub;
+        // (3) deflation windows, bottom up.  [0, top) final undeflatable, [top, bottom - carried) unchecked,
+        // [bottom - carried, bottom) carried undeflatable, [bottom, nw) deflated
+        int top = 0, bottom = nw, carried = 0;
+        while (top < bottom - carried) {
+            int const we = bottom;
+            int wb = std::max(top, we - WDD);
+            if (wb > top && asub[wb - 1] != 0.0) wb++;          // do not cut a 2x2 block
+            int const w = we - wb, ldh = host_ld(w);
+            large_window_to_host(L, wb, w, ldh); prof_laed_windows++;
+            int und = 0;
+            int const rej = host::gep_deflate_window(w, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, sp.data() + wb,
+                sub, thres, carried, &und);
+            large_window_to_device(L, wb, w, ldh);
+            large_window_updates(L, nw, wb, w);
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            for (int i = 0; i + 1 < w; i++) asub[wb + i] = ws.hA[(size_t)i * ldh + i + 1];
+            bottom = wb + und; carried = und;
+            if (rej) { top = bottom; carried = 0; break; }      // swap rejected: stop testing
+            if (wb == top) { top = bottom; carried = 0; break; }
+            if (carried >= WDD / 2 || bottom - carried - top < 2) {
+                // flush the carried blocks to the top of the AED window (reorder chain)
+                int ge = bottom;                                // group = [ge - carried, ge)
+                std::vector<int> marks(WD);
+                while (ge - carried > top) {
+                    int rb = std::max(top, ge - WD);
+                    if (rb > top && asub[rb - 1] != 0.0) rb++;
+                    int const rw = ge - rb, rldh = host_ld(rw);
+                    large_window_to_host(L, rb, rw, rldh);
+                    for (int i = 0; i < rw; i++) marks[i] = (i >= rw - carried) ? 1 : 0;
+                    int failed = 0;
+                    int const placed = host::gep_reorder_window(rw, ws.hA, rldh, ws.hB, rldh, ws.hQ, rldh, ws.hZ, rldh,
+                        marks.data(), &failed);
+                    {   // spike segment <- spike * Ql
+                        std::vector<double> t(rw);
+                        for (int j = 0; j < rw; j++) { double v = 0.0; for (int k = 0; k < rw; k++) v += sp[rb + k] * ws.hQ[(size_t)j * rldh + k]; t[j] = v; }
+                        for (int j = 0; j < rw; j++) sp[rb + j] = t[j];
+                    }
+                    large_window_to_device(L, rb, rw, rldh);
+                    large_window_updates(L, nw, rb, rw);
+                    SN_HIP_CHECK(hipStreamSynchronize(s));
+                    for (int i = 0; i + 1 < rw; i++) asub[rb + i] = ws.hA[(size_t)i * rldh + i + 1];
+                    if (failed || placed != carried) { top = bottom; carried = 0; ge = top; break; }
+                    ge = rb + carried;
+                }
+                if (carried > 0) { top += carried; carried = 0; }
+            }
+        }
+        if (carried > 0) { top = bottom; carried = 0; }
+        int const ns = top, nd = nw - ns;
+        double const tl2 = wall(); prof_laed[1] += tl2 - tl1;
+        // the window pencil on the host: shifts now, the deflated diagonal blocks for the caller later
+        int const ldw = host_ld(nw);
+        auto window_pencil_to_host = [&]() {
+            SN_HIP_CHECK(hipMemcpy2DAsync(ws.hA, (size_t)ldw * 8, L.dA, (size_t)ld * 8, (size_t)nw * 8, nw, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipMemcpy2DAsync(ws.hB, (size_t)ldw * 8, L.dB, (size_t)ld * 8, (size_t)nw * 8, nw, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+        };
+        window_pencil_to_host();
+        res.shifts = host::gep_window_shifts(ns >= 2 ? ns : nw, ws.hA, ldw, ws.hB, ldw, sr, si);
+        res.deflated = nd;
+        if (nd == 0) return res;                // the caller's pencil was never touched
+        // (4) spike + Hessenberg-triangular form of the undeflated part
+        for (int j = 0; j < nw; j++) spike[j] = (j < ns) ? sp[j] : 0.0;
+        if (ns > 1 && sub != 0.0) {
+            int const np = ns + 1;
+            set_matrix(s, np, np, 0.0, 0.0, L.dPA, ld);
+            set_matrix(s, np, np, 0.0, 1.0, L.dPB, ld);
+            set_matrix(s, np, np, 0.0, 1.0, L.dPQ, ld);
+            set_matrix(s, np, np, 0.0, 1.0, L.dPZ, ld);
+            copy_matrix(s, ns, ns, L.dA, ld, L.dPA + ld + 1, ld);
+            copy_matrix(s, ns, ns, L.dB, ld, L.dPB + ld + 1, ld);
+            SN_HIP_CHECK(hipMemcpyAsync(L.dPA + 1, sp.data(), (size_t)ns * 8, hipMemcpyHostToDevice, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));      // sp is pageable
+            int const hrc = hessenberg_triangular_device(s, np, L.dPA, ld, L.dPB, ld, L.dPQ, ld, L.dPZ, ld, nullptr);
+            if (hrc != 0) { res.failed = 1; res.deflated = 0; return res; }
+            // Uq = PQ(1:,1:), Uz = PZ(1:,1:):  (A,B)(0:ns, ns:nw) <- Uq^T . ;  Q(:,0:ns) <- . Uq ;  Z(:,0:ns) <- . Uz
+            double const *Uq = L.dPQ + ld + 1, *Uz = L.dPZ + ld + 1;
+            for (double *M : {L.dA, L.dB}) {
+                dgemm(s, 'T', 'N', ns, nd, ns, 1.0, Uq, ld, M + (size_t)ns * ld, ld, 0.0, L.dTmp, ld);
+                copy_matrix(s, ns, nd, L.dTmp, ld, M + (size_t)ns * ld, ld);
+            }
+            dgemm(s, 'N', 'N', nw, ns, ns, 1.0, L.dQ, ld, Uq, ld, 0.0, L.dTmp, ld);
+            copy_matrix(s, nw, ns, L.dTmp, ld, L.dQ, ld);
+            dgemm(s, 'N', 'N', nw, ns, ns, 1.0, L.dZ, ld, Uz, ld, 0.0, L.dTmp, ld);
+            copy_matrix(s, nw, ns, L.dTmp, ld, L.dZ, ld);
+            copy_matrix(s, ns, ns, L.dPA + ld + 1, ld, L.dA, ld);
+            copy_matrix(s, ns, ns, L.dPB + ld + 1, ld, L.dB, ld);
+            SN_HIP_CHECK(hipMemcpyAsync(spike, L.dPA + 1, 8, hipMemcpyDeviceToHost, s));
+            SN_HIP_CHECK(hipStreamSynchronize(s));
+            for (int r = 1; r < ns; r++) spike[r] = 0.0;
+            st.gemm_flops += 2.0 * ns * ns * (2.0 * nd + 2.0 * nw);
+        }
+        double const tl3 = wall(); prof_laed[2] += tl3 - tl2;
+        // (5) window back into the pencil, coupling entry, off-window updates of A, B, Q, Z
+        copy_matrix(s, nw, nw, L.dA, ld, A + (size_t)kw * ldA + kw, ldA);
+        copy_matrix(s, nw, nw, L.dB, ld, B + (size_t)kw * ldB + kw, ldB);
+        if (sub != 0.0)
+            hipLaunchKernelGGL(gep_set_entry_kernel, dim3(1), dim3(1), 0, s, A + (size_t)(kw - 1) * ldA + kw, spike[0]);
+        apply_transform(kw, nw, L.dQ, L.dZ, ld);
+        window_pencil_to_host();                // the caller reads the deflated diagonal blocks from the host copy
+        prof_laed[3] += wall() - tl3;
+        return res;
+    }
+
     // Q and Z updates of the window steps: issued after the sweep's critical path, on the lazy
     // stream, so that they execute while the host reduces the AED windows that follow
     struct LazyItem { SweepStep step; int ev; };
@@ -645,7 +854,7 @@ struct GepDriver {
 
 int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB, int ldB,
     double *dQ, int ldQ, double *dZ, int ldZ, double *real, double *imag, double *beta,
-    SchurParams const &prm, SchurStats *stats)
+    SchurParams const &prm, SchurStats *stats, int level)
 {
     static hipStream_t own = nullptr;
     static hipEvent_t fence = nullptr;
@@ -667,7 +876,10 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     // residual of 74 u, against 7.0 s and 499 u for window 160 / nibble 40 % (137 sweeps).
     // If the AEDs stop deflating (less than 6 % of the window) the sweeps take over as usual.
     int const nw_rule = tuning().gep_window > 0 ? tuning().gep_window : 64;
-    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, 768) : std::min(nw_rule, std::max(16, n / 8));
+    // (a window the caller asks for is taken as asked: up to aed_parallel_hard_limit rows by the sequential host
+    // kernel, above it by the blocked device path large_aed -- rounds 2-4 silently clamped it to 768)
+    int nw_conf = prm.aed_window_size > 0 ? std::min(prm.aed_window_size, n) : std::min(nw_rule, std::max(16, n / 8));
+    int const hard_limit = prm.aed_parallel_hard_limit > 0 ? prm.aed_parallel_hard_limit : 300;
     int ns_conf = prm.shift_count > 0 ? prm.shift_count : std::min(100, std::max(2, 2 * nw_conf / 3));
     ns_conf = std::min(ns_conf, 9 * nw_conf / 10);
     ns_conf = std::max(2, ns_conf - ns_conf % 2);
@@ -676,8 +888,8 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     int const nibble = prm.aed_nibble > 0 ? prm.aed_nibble : 6;
     int const iter_limit = prm.iteration_limit > 0 ? prm.iteration_limit : 300;
 
-    GepWorkspace &ws = g_gws;
-    int const wmax = std::max({nw_conf + nw_conf / 2 + 8, small_limit, 2 * GWS});
+    GepWorkspace &ws = g_gws[level];
+    int const wmax = std::min(n + 8, std::max({nw_conf + nw_conf / 2 + 8, small_limit, 2 * GWS}));
     // Shift multiplicity (see schur.hip): every shift pair of an AED drives `reuse` bulges of the following
     // sweep.  Round 2 left it off for pencils -- at n = 12000 a multiplicity of 4 raised the residual from
     // 460 u to 690 u then.  Since the reflectors are scaled by exact powers of two the extra chain passes
@@ -772,20 +984,29 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         if (stagnation > 0) nw = std::min(size, std::min(wmax, nw + nw / 20 * stagnation + 2));
         int const kw = ihi - nw;
         double const sub = (kw > ilo) ? ws.hSub[kw - 1] : 0.0;
-        d.download_windows(kw, nw);
-        double t_aed0 = wall();
         int const ldh = GepDriver::host_ld(nw);
-        host::AedResult ar = host::gep_aed_window(nw, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, sub, thres,
-            spike.data(), sr.data(), si.data(), thres_b);
+        // windows above aed_parallel_hard_limit: the blocked device path (level 0 only: its own windows are small)
+        bool const blocked = level == 0 && nw > hard_limit && nw >= 2 * GWS;
+        host::AedResult ar;
+        double t_aed0 = wall();
+        if (blocked) ar = d.large_aed(kw, nw, sub, thres, prm, spike.data(), sr.data(), si.data());
+        else {
+            d.download_windows(kw, nw);
+            t_aed0 = wall();
+            ar = host::gep_aed_window(nw, ws.hA, ldh, ws.hB, ldh, ws.hQ, ldh, ws.hZ, ldh, sub, thres,
+                spike.data(), sr.data(), si.data(), thres_b);
+        }
         d.st.aed_host_s += wall() - t_aed0;
         d.st.aeds++;
         if (ar.failed) { rc = STARNEIG_DID_NOT_CONVERGE; break; }
         if (ar.deflated > 0) {
-            d.upload_windows(kw, nw);
-            if (kw > ilo)
-                hipLaunchKernelGGL(gep_set_entry_kernel, dim3(1), dim3(1), 0, s,
-                    dA + (size_t)(kw - 1) * ldA + kw, spike[0]);
-            d.apply_transform(kw, nw, ws.dQl, ws.dZl, nw);
+            if (!blocked) {
+                d.upload_windows(kw, nw);
+                if (kw > ilo)
+                    hipLaunchKernelGGL(gep_set_entry_kernel, dim3(1), dim3(1), 0, s,
+                        dA + (size_t)(kw - 1) * ldA + kw, spike[0]);
+                d.apply_transform(kw, nw, ws.dQl, ws.dZl, nw);
+            }
             SN_HIP_CHECK(hipStreamSynchronize(s));
             if (real) {
                 int const off = nw - ar.deflated;
@@ -844,9 +1065,10 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
     SN_HIP_CHECK(hipEventElapsedTime(&d.st.total_ms, e0, e1));
     SN_HIP_CHECK(hipEventDestroy(e0)); SN_HIP_CHECK(hipEventDestroy(e1));
     if (tuning().schur_profile)
-        fprintf(stderr, "[qz] total %.3f s: aed_host %.3f, wait %.3f, push_inf %.3f s for %d infinite eigenvalues (%d windows); n %d sweeps %d aeds %d\n",
-            d.st.total_ms * 1e-3, d.st.aed_host_s, d.st.wait_s, d.prof_inf_s, d.st.inf_deflated, d.prof_inf_windows,
-            n, d.st.sweeps, d.st.aeds);
+        fprintf(stderr, "[qz level %d] total %.3f s: aed_host %.3f, wait %.3f, push_inf %.3f s for %d infinite eigenvalues (%d windows); n %d sweeps %d aeds %d; "
+            "blocked AEDs %d (%d deflation windows): Schur form %.3f, deflation %.3f, restoration %.3f, rest %.3f s\n",
+            level, d.st.total_ms * 1e-3, d.st.aed_host_s, d.st.wait_s, d.prof_inf_s, d.st.inf_deflated, d.prof_inf_windows,
+            n, d.st.sweeps, d.st.aeds, d.prof_laed_calls, d.prof_laed_windows, d.prof_laed[0], d.prof_laed[1], d.prof_laed[2], d.prof_laed[3]);
     if (stats) *stats = d.st;
     return rc;
 }

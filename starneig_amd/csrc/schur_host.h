@@ -38,6 +38,11 @@ void gep_ht_reduce(int n, int ilo, int ihi, double *A, int lda, double *B, int l
     double *Q, int ldq, double *Z, int ldz, int nq);
 int gep_move_block_up(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, int nq, int from, int to);
+int gep_window_shifts(int hi, double const *A, int lda, double const *B, int ldb, double *sr, double *si);
+int gep_deflate_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq, double *Z, int ldz,
+    double *spike, double sub, double thres, int carried, int *undeflated);
+int gep_reorder_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq, double *Z, int ldz,
+    int *sel, int *failed);
 AedResult gep_aed_window(int nw, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, double sub, double thres, double *spike, double *sr, double *si,
     double thres_b = -1.0);

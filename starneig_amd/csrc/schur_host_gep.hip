@@ -867,6 +867,114 @@ int gep_move_block_up(int nw, double *A_, int lda, double *B_, int ldb, double *
 }
 
 
+// Shifts of the next sweep: the finite, non-zero eigenvalues of the leading hi x hi part of a window in
+// generalized Schur form, ordered by magnitude, complex pairs adjacent (schur/cpu_utils.c:3493-3594).
+int gep_window_shifts(int hi, double const *A_, int lda, double const *B_, int ldb, double *sr, double *si)
+{
+    std::vector<double> ar(hi), ai(hi), be(hi);
+    gep_extract_eigenvalues(hi, A_, lda, B_, ldb, ar.data(), ai.data(), be.data());
+    std::vector<double> wr, wi;
+    for (int k = 0; k < hi; k++)
+        if (be[k] != 0.0) {
+            double re = ar[k] / be[k], im = ai[k] / be[k];
+            if (std::isfinite(re) && std::isfinite(im) && !(re == 0.0 && im == 0.0)) { wr.push_back(re); wi.push_back(im); }
+        }
+    int const cnt = (int)wr.size();
+    std::vector<int> idx(cnt);
+    for (int k = 0; k < cnt; k++) idx[k] = k;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        return std::fabs(wr[a]) + std::fabs(wi[a]) < std::fabs(wr[b]) + std::fabs(wi[b]); });
+    for (int k = 0; k < cnt; k++) { sr[k] = wr[idx[k]]; si[k] = wi[idx[k]]; }
+    for (int k = 0; k + 2 < cnt; k += 2)
+        if (si[k] != -si[k + 1]) {
+            double r0 = sr[k], i0 = si[k];
+            sr[k] = sr[k + 1]; sr[k + 1] = sr[k + 2]; sr[k + 2] = r0;
+            si[k] = si[k + 1]; si[k + 1] = si[k + 2]; si[k + 2] = i0;
+        }
+    return cnt;
+}
+
+// ---- one deflation window of the blocked AED on a pencil (the generalized twin of host::deflate_window;
+// reference schur/cpu.c:638-1006 starneig_cpu_deflate with B != NULL, driven by schur/core.c:1070-1252) ----
+// (A, B): w x w diagonal window of the AED window's generalized Schur form; the bottom `carried` rows hold
+// blocks an earlier deflation window found undeflatable, the rows above them are unchecked.  spike[0:w] is
+// the window's segment of the spike sub * Q_aed(0,:).  Q, Z: identity on entry, the accumulated swaps on
+// return.  The carried blocks go to the top of the window, then the unchecked blocks are tested from the
+// bottom (a block is tested when it is the last undeflated one; an undeflatable block joins the carried
+// ones at the top).  On return [0, *undeflated) holds the undeflatable blocks, [*undeflated, w) the deflated
+// ones, spike <- spike * Q.  Returns 0, or 1 if a swap was rejected (everything above counts as undeflatable).
+int gep_deflate_window(int w, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq, double *Z_, int ldz,
+    double *spike, double sub, double thres, int carried, int *undeflated)
+{
+    Mat A{A_, lda}, Q{Q_, ldq};
+    int rc = 0, top = 0;
+    bool tested = false;
+    for (int i = w - carried; i < w;) {
+        int const bs = (i + 1 < w && A(i + 1, i) != 0.0) ? 2 : 1;
+        if (i > top) {
+            int const at = gep_move_block_up(w, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, w, i, top);
+            if (at != top) { *undeflated = w; rc = 1; tested = true; break; }   // nothing can be tested behind it
+        }
+        top += bs; i += bs;
+    }
+    if (!tested) {
+        const double ulp = DBL_EPSILON, smlnum = DBL_MIN * ((double)w / ulp);
+        auto cur = [&](int col) { double v = 0.0; for (int k = 0; k < w; k++) v += spike[k] * Q(k, col); return v; };
+        int i = w - 1;
+        while (top <= i) {
+            bool const two = (top <= i - 1 && A(i, i - 1) != 0.0);
+            double sp = std::fabs(cur(i));
+            if (two) sp = std::max(sp, std::fabs(cur(i - 1)));
+            bool deflatable;
+            if (thres > 0.0) deflatable = sp < thres;
+            else {
+                double foo = std::fabs(A(i, i));
+                if (two) foo += std::sqrt(std::fabs(A(i, i - 1))) * std::sqrt(std::fabs(A(i - 1, i)));
+                if (foo == 0.0) foo = std::fabs(sub);
+                deflatable = sp < std::max(smlnum, ulp * foo);
+            }
+            int const bs = two ? 2 : 1;
+            if (deflatable) i -= bs;
+            else {
+                int const at = gep_move_block_up(w, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, w, i - bs + 1, top);
+                if (at != top) { top = i + 1; rc = 1; break; }
+                top += bs;
+            }
+        }
+        *undeflated = top;
+    }
+    std::vector<double> ns(w);
+    for (int j = 0; j < w; j++) { double v = 0.0; for (int k = 0; k < w; k++) v += spike[k] * Q(k, j); ns[j] = v; }
+    for (int j = 0; j < w; j++) spike[j] = ns[j];
+    return rc;
+}
+
+// The marked diagonal blocks of a w x w window of a generalized Schur form to the top of the window, in their
+// order (the generalized twin of host::reorder_window; LAPACK dtgsen's loop of dtgexc calls).  sel[i] != 0
+// marks the rows of selected blocks; on return sel holds the marks of the rows in their new order.  Returns
+// the number of rows of selected blocks now at the top; *failed is set when a swap was rejected.
+int gep_reorder_window(int w, double *A_, int lda, double *B_, int ldb, double *Q_, int ldq, double *Z_, int ldz,
+    int *sel, int *failed)
+{
+    Mat A{A_, lda};
+    *failed = 0;
+    int top = 0, i = 0;
+    while (i < w) {
+        int const bs = (i + 1 < w && A(i + 1, i) != 0.0) ? 2 : 1;
+        bool const marked = sel[i] != 0 || (bs == 2 && sel[i + 1] != 0);
+        if (!marked) { i += bs; continue; }
+        if (i > top) {
+            int const at = gep_move_block_up(w, A_, lda, B_, ldb, Q_, ldq, Z_, ldz, w, i, top);
+            for (int r = i + bs - 1; r >= at + bs; r--) sel[r] = 0;
+            for (int r = at; r < at + bs; r++) sel[r] = 1;
+            if (at != top) { *failed = 1; return top; }
+        } else for (int r = i; r < i + bs; r++) sel[r] = 1;
+        top += bs;
+        i += bs;
+    }
+    return top;
+}
+
 // Aggressive early deflation on a host window of the pencil (reference
 // perform_aggressively_deflate, cpu_utils.c:2837-3046, generalized branches): eigenvalues
 // whose spike entries are below the threshold are deflated, the others are reordered to the
@@ -925,29 +1033,7 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
         } } } report{prof, t0, t1, t2, now, nw, nd};
     for (int j = 0; j < nw; j++) spike[j] = sub * Q(0, j);
     // shifts: finite eigenvalues of the undeflated part (of everything if that is too small)
-    {
-        int const hi = (ns >= 2) ? ns : nw;
-        gep_extract_eigenvalues(hi, A_, lda, B_, ldb, ar.data(), ai.data(), be.data());
-        std::vector<double> wr, wi;
-        for (int k = 0; k < hi; k++)
-            if (be[k] != 0.0) {
-                double re = ar[k] / be[k], im = ai[k] / be[k];
-                if (std::isfinite(re) && std::isfinite(im) && !(re == 0.0 && im == 0.0)) { wr.push_back(re); wi.push_back(im); }
-            }
-        int const cnt = (int)wr.size();
-        std::vector<int> idx(cnt);
-        for (int k = 0; k < cnt; k++) idx[k] = k;
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
-            return std::fabs(wr[a]) + std::fabs(wi[a]) < std::fabs(wr[b]) + std::fabs(wi[b]); });
-        for (int k = 0; k < cnt; k++) { sr[k] = wr[idx[k]]; si[k] = wi[idx[k]]; }
-        for (int k = 0; k + 2 < cnt; k += 2)
-            if (si[k] != -si[k + 1]) {
-                double r0 = sr[k], i0 = si[k];
-                sr[k] = sr[k + 1]; sr[k + 1] = sr[k + 2]; sr[k + 2] = r0;
-                si[k] = si[k + 1]; si[k + 1] = si[k + 2]; si[k + 2] = i0;
-            }
-        res.shifts = cnt;
-    }
+    res.shifts = gep_window_shifts((ns >= 2) ? ns : nw, A_, lda, B_, ldb, sr, si);
     if (nd == 0) return res;
     for (int j = ns; j < nw; j++) spike[j] = 0.0;
     if (ns > 1 && sub != 0.0) {
@@ -984,6 +1070,14 @@ AedResult gep_aed_window(int nw, double *A_, int lda, double *B_, int ldb, doubl
 #ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- test hooks (host-only; NOT part of the public C-ABI, used by tests/ on CPU) -------
 extern "C" {
+__attribute__((visibility("default")))
+int sn_internal_gep_deflate_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq, double *Z, int ldz,
+    double *spike, double sub, double thres, int carried, int *undeflated)
+{ return sn::host::gep_deflate_window(w, A, lda, B, ldb, Q, ldq, Z, ldz, spike, sub, thres, carried, undeflated); }
+__attribute__((visibility("default")))
+int sn_internal_gep_reorder_window(int w, double *A, int lda, double *B, int ldb, double *Q, int ldq, double *Z, int ldz,
+    int *sel, int *failed)
+{ return sn::host::gep_reorder_window(w, A, lda, B, ldb, Q, ldq, Z, ldz, sel, failed); }
 __attribute__((visibility("default")))
 void sn_internal_gep_extract_eigenvalues(int n, double const *S, int lds, double const *T, int ldt,
     double *ar, double *ai, double *be)

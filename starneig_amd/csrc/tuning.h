@@ -14,6 +14,8 @@ struct Tuning {
     int hess_side_cus = 0;          // SN_HESS_SIDE_CUS: CU mask of the side stream (0 = none)
     bool hess_noside = false;       // SN_HESS_NOSIDE: delayed updates on the critical stream
     int hess_fold = 0;              // SN_HESS_FOLD: fold of the sharded gemv's partials (0 release/acquire ticket, 1 sc1 only, 2 own launch)
+    bool team_pooled_stream = false;// SN_TEAM_POOLED_STREAM: the ranks' streams plain (pooled hardware queues) as in round 4 (reproducer)
+    bool team_verify = false;       // SN_TEAM_VERIFY: hash every in-process collective's result on every rank and compare
     int team_fail_rank = -1;        // SN_TEAM_FAIL_RANK: this rank of the one-process team reports "no memory" (tests of the error path)
     // Schur
     bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
@@ -21,6 +23,7 @@ struct Tuning {
     int schur_helpers = -1;         // SN_SCHUR_HELPERS: helper threads of the host window kernels (0 = none, -1 = five if the node has the cores)
     int schur_reuse = 0;            // SN_SCHUR_REUSE: fixed shift multiplicity (0 = adaptive)
     bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
+    bool schur_chase_ulds = false;  // SN_SCHUR_CHASE_ULDS: the chase kernel of rounds 1-4 (accumulated factor in LDS, 150 KB per window)
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
     bool aed_profile = false;       // SN_AED_PROFILE
     bool schur_hs_prio = true;      // SN_SCHUR_HS_PRIO=0: lazy H stream at the priority of the lazy Q stream (else one level above)

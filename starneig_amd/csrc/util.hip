@@ -24,12 +24,15 @@ Tuning const &tuning()
         t.hess_noside = getb("SN_HESS_NOSIDE");
         t.hess_fold = geti("SN_HESS_FOLD", t.hess_fold);
         t.team_fail_rank = geti("SN_TEAM_FAIL_RANK", t.team_fail_rank);
+        t.team_verify = getb("SN_TEAM_VERIFY");
+        t.team_pooled_stream = getb("SN_TEAM_POOLED_STREAM");
         t.hess_side_cus = geti("SN_HESS_SIDE_CUS", 0);
         t.schur_nolazyrows = getb("SN_SCHUR_NOLAZYROWS");
         t.schur_lazy_batch = geti("SN_SCHUR_LAZY_BATCH", t.schur_lazy_batch);
         t.schur_helpers = geti("SN_SCHUR_HELPERS", t.schur_helpers);
         t.schur_reuse = std::max(0, std::min(8, geti("SN_SCHUR_REUSE", 0)));
         t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
+        t.schur_chase_ulds = getb("SN_SCHUR_CHASE_ULDS");
         t.schur_profile = getb("SN_SCHUR_PROFILE");
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);

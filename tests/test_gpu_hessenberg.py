@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from helpers import U, WARN_U, elementwise_tolerance, to_device, to_host
+from helpers import U, WARN_U, elementwise_tolerance, to_device, to_host, torch_check
 from test_oracle import partial_input
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,51 @@ def test_panel_widths(node, pw):
     A, Q = run_host_api(node, A0, panel_width=pw)
     assert O.count_below_subdiagonal(A) == 0
     compare_with_oracle(A, Q, A0, panel_width=pw)
+
+
+_ORACLE_4000 = {}
+
+
+@pytest.mark.parametrize("pw", [45, 314, 400, 410, 170, 35, 303])
+def test_ctest_hessenberg_panel_widths_n4000(node, pw):
+    """hessenberg-panel-{45,314,400,410,170,35,303}: `--experiment hessenberg --n 4000 --panel-width pw`
+    (test/CMakeLists.txt:367-388), at the reference's own size: exact Hessenberg structure, the reference's
+    residual hooks, and H elementwise against the oracle (ONE oracle reduction at n = 4000 serves the seven
+    widths: the panel width only re-associates the sums, and the tolerance 8 sqrt(n) u ||A||_F is the one the
+    same-width comparisons at n = 400 use)."""
+    n = 4000
+    A0 = O.random_fullpos(n)
+    A, Q = run_host_api(node, A0, panel_width=pw)
+    assert O.count_below_subdiagonal(A) == 0
+    if "H" not in _ORACLE_4000:
+        Ao = A0.copy(order="F"); Qo = O.identity(n, ld=A0.shape[0])
+        O.hessenberg(Ao, Qo)
+        _ORACLE_4000["H"], _ORACLE_4000["Q"] = Ao, Qo
+    Ao, Qo = _ORACLE_4000["H"], _ORACLE_4000["Q"]
+    tol = elementwise_tolerance(n)
+    err = np.abs(A[:n] - Ao[:n]).max() / np.linalg.norm(A0[:n])
+    errq = np.abs(Q[:n] - Qo[:n]).max()
+    print(f"panel width {pw}: max|H - H_oracle| / ||A|| = {err / tol:.3f} tol, max|Q - Q_oracle| = {errq / (tol * np.sqrt(n)):.3f} tol")
+    assert err <= tol and errq <= tol * np.sqrt(n)
+    assert np.array_equal(np.sign(np.diag(A[:n], -1)), np.sign(np.diag(Ao[:n], -1)))
+    res, orth = torch_check(to_device(Q), to_device(A), to_device(A0), n)
+    assert res < 1.5 * 15 and orth < 1.5 * 11, (res, orth)      # 1.5 x the reference's published n = 4000 values
+
+
+def test_ctest_hessenberg_partial_3569(node):
+    """hessenberg-partial-3569: `--experiment partial-hessenberg --n 3569 --begin 892 --end 2676`
+    (test/CMakeLists.txt:390-405), elementwise against the oracle on the same range."""
+    n = 3569
+    begin, end = n // 4, 3 * n // 4
+    A0 = partial_input(n, begin, end)
+    A, Q = run_host_api(node, A0, begin=begin, end=end)
+    H = A[:n]
+    for c in range(n - 1):
+        k = 2 if begin <= c < end - 1 else 1
+        assert np.all(H[c + k:, c] == 0.0)
+    compare_with_oracle(A, Q, A0, begin=begin, end=end)
+    res, orth = torch_check(to_device(Q), to_device(A), to_device(A0), n)
+    assert res < WARN_U and orth < WARN_U
 
 
 @pytest.mark.parametrize("n,begin,end", [(47, 3, 40), (88, 0, 50), (88, 20, 88), (333, 100, 250), (554, 1, 553)])

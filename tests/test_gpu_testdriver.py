@@ -195,6 +195,71 @@ def test_ctest_schur_standard_n4000(node, aed, parallel, decouple):
     assert abs(real.sum() - tr) <= 1e-9 * float(torch.diagonal(tH0[:, :n]).abs().sum())
 
 
+_GSWEEP_INPUT = {}
+
+
+def gsweep_input(n, decouple, set_to_inf):
+    """the driver's generalized `random` input on the device: H, R, Q, Z and the originals Q H Z^T, Q R Z^T"""
+    import torch
+    key = (n, decouple, set_to_inf)
+    if key not in _GSWEEP_INPUT:
+        _GSWEEP_INPUT.clear()
+        H0, Q0, R0, Z0 = O.schur_random_input(n, generalized=True, decouple=decouple, set_to_inf=set_to_inf)
+        if decouple:
+            assert int((np.diag(H0[:n], -1) == 0.0).sum()) == decouple
+        if set_to_inf:
+            assert int((np.diag(R0[:n]) == 0.0).sum()) == set_to_inf
+        tH0, tR0, tQ0, tZ0 = to_device(H0), to_device(R0), to_device(Q0), to_device(Z0)
+
+        def original(t):
+            out = torch.zeros_like(t)
+            out[:, :n] = (tQ0[:, :n].T @ t[:, :n].T @ tZ0[:, :n]).T     # (Q0 M Z0^T)^T = Z0 M^T Q0^T
+            return out
+        _GSWEEP_INPUT[key] = (tH0, tR0, tQ0, tZ0, original(tH0), original(tR0))
+    return _GSWEEP_INPUT[key]
+
+
+@pytest.mark.parametrize("decouple", [False, True], ids=["plain", "decouple-3-set-to-inf-100"])
+@pytest.mark.parametrize("parallel", [False, True], ids=["sequential", "parallel"])
+@pytest.mark.parametrize("aed", [-1, 50, 500, 1000, 2000], ids=lambda a: "aed-default" if a < 0 else f"aed-{a}")
+def test_ctest_schur_generalized_n4000(node, aed, parallel, decouple):
+    """schur-generalized-[decouple-]{sequential,parallel}-aed-{default,50,500,1000,2000}: `--experiment schur
+    --generalized --n 4000 --aed-window-size w --aed-parallel-{soft,hard}-limit {9999 | 1} [--decouple 3
+    --set-to-inf 100]` (test/CMakeLists.txt:509-535; generator test/schur/experiment.c:100-214), under the
+    driver's default hooks at the reference's own thresholds: generalized Schur form, the `eigenvalues` hook
+    (warn 10^3 u, fail 10^4 u, hooks.c:787-788), residuals and orthogonality below 500 u; the planted
+    infinite eigenvalues must come back with beta = 0 exactly.  `parallel` takes the blocked AED of the
+    pencil path (GepDriver::large_aed) for every window above 128 rows, `sequential` the host kernel at
+    whatever size was asked for (round 4 silently clamped the window to 768)."""
+    import torch
+    n = 4000
+    if not parallel and aed >= 2000 and decouple:
+        pytest.skip("the sequential 2000-row host AED is covered by the plain variant (minutes per run)")
+    tH0, tR0, tQ0, tZ0, tA0, tB0 = gsweep_input(n, 3 if decouple else 0, 100 if decouple else 0)
+    conf = node.schur_init_conf()
+    conf.aed_window_size = aed
+    conf.aed_parallel_soft_limit = conf.aed_parallel_hard_limit = 1 if parallel else 9999
+    tH, tR, tQ, tZ = tH0.clone(), tR0.clone(), tQ0.clone(), tZ0.clone()
+    rc, ar, ai, be, st = node.gep_schur_device(tH, tR, tQ, tZ, n=n, conf=conf)
+    torch.cuda.synchronize()
+    assert rc == 0
+    ra, oq, oz = torch_check_pencil(tQ, tH, tZ, tA0, n)
+    rb, _, _ = torch_check_pencil(tQ, tR, tZ, tB0, n)
+    print(f"aed={aed} parallel={parallel} decouple={decouple}: residuals {ra:.1f} / {rb:.1f} u orthogonality {oq:.1f} / {oz:.1f} u "
+          f"sweeps {st['sweeps']} aeds {st['aeds']} infinite {int((be == 0.0).sum())} {st['total_ms'] / 1e3:.2f} s "
+          f"(host AED {st['aed_host_s']:.2f} s)")
+    assert max(ra, rb, oq, oz) < WARN_U, (ra, rb, oq, oz)
+    Sm, Tm = to_host(tH), to_host(tR)
+    assert O.check_gep_schur_form(Sm, Tm) == 0
+    if decouple:
+        # the 100 planted zeros of R's diagonal come back as infinite eigenvalues with beta = 0 exactly -- beside
+        # those the random triangular factor produces by itself (25 in the plain run: cond(R) ~ 1e18)
+        assert int((be == 0.0).sum()) >= 100
+    er, ei, eb = O.gep_extract_eigenvalues(Sm, Tm)
+    hook = O.eigenvalues_check((er, ei, eb), (ar, ai, be))          # the reference's thresholds: 10^3 / 10^4 u
+    assert hook["failures"] == 0 and hook["warnings"] == 0, hook
+
+
 @pytest.mark.parametrize("n", [4000, 8000])
 def test_check_device_against_independent_fp64(node, n):
     """(3) after the Hessenberg leg: the library's residual / orthogonality against torch.matmul"""
@@ -328,5 +393,5 @@ def test_ctest_simple_generalized_n5000(node):
     print(f"simple-schur-generalized: {ra:.1f} / {rb:.1f} u, {oq:.1f} / {oz:.1f} u")
     assert max(ra, rb, oq, oz) < WARN_U
     er, ei, eb = O.gep_extract_eigenvalues(H, R)
-    hook = O.eigenvalues_check((er, ei, eb), (ar, ai, be), warn=1e5, fail=1e6)   # (nearly real pairs: see tests/test_gpu_gep.py)
-    assert hook["failures"] == 0, hook
+    hook = O.eigenvalues_check((er, ei, eb), (ar, ai, be))          # the reference's thresholds: 10^3 / 10^4 u
+    assert hook["failures"] == 0 and hook["warnings"] == 0, hook

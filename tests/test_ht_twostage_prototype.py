@@ -1,0 +1,38 @@
+"""CPU: the numpy prototype of the two-stage Hessenberg-triangular reduction (scratch/ht2_proto.py) that
+DESIGN.md section 4d's worked estimate rests on -- stage 1 to r-Hessenberg-triangular form (QR of 2r x r blocks
+of A, RQ of the bottom rows of the filled diagonal blocks of B), stage 2 a Householder bulge chase with
+'opposite' reflectors from the right (Kagstrom, Kressner, Quintana-Orti, Quintana-Orti 2008).  Not a product
+path: it documents that the algorithm is backward stable on the inputs the rotation path is kept for
+(singular B included) before its cost on the GPU is estimated."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("ht2_proto", os.path.join(ROOT, "scratch", "ht2_proto.py"))
+P = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(P)
+U = 2.0 ** -52
+
+
+@pytest.mark.parametrize("n,r,singular", [(40, 4, False), (97, 8, True), (150, 16, False)])
+def test_two_stage_reduction_is_backward_stable(n, r, singular):
+    rng = np.random.default_rng(n)
+    A0 = rng.standard_normal((n, n)); B0 = np.triu(rng.standard_normal((n, n)))
+    if singular:
+        B0[10, 10] = 0.0; B0[50, 50] = 0.0
+    A, B = A0.copy(), B0.copy(); Q = np.eye(n); Z = np.eye(n)
+    P.stage1(A, B, Q, Z, r)
+    assert all(A[i, c] == 0.0 for c in range(n) for i in range(c + r + 1, n))      # r-Hessenberg
+    assert np.abs(np.tril(B, -1)).max() == 0.0
+    log = []
+    P.stage2(A, B, Q, Z, r, log)
+    assert np.abs(np.tril(A, -2)).max() == 0.0 and np.abs(np.tril(B, -1)).max() == 0.0
+    assert np.linalg.norm(Q @ A @ Z.T - A0) <= 100 * U * np.linalg.norm(A0)
+    assert np.linalg.norm(Q @ B @ Z.T - B0) <= 100 * U * np.linalg.norm(B0)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 100 * U * np.sqrt(n)
+    assert np.linalg.norm(Z.T @ Z - np.eye(n)) <= 100 * U * np.sqrt(n)
+    # the chase of stage 2: ~ n^2 / (2 r) steps of one left and one right reflector of length <= r
+    assert abs(len(log) - n * n / (2.0 * r)) <= 0.35 * n * n / (2.0 * r)

@@ -231,3 +231,119 @@ def test_returned_eigenvalues_of_2x2_blocks_are_dlag2_bit_for_bit():
         assert np.array_equal(oar, ar) and np.array_equal(oai, ai) and np.array_equal(obe, be)
         checked += 1
     assert checked > 800
+
+
+def _schur_window(w, seed):
+    """a w x w generalized Schur form (S, T) with its factors, from the small QZ kernel"""
+    rng = np.random.RandomState(seed)
+    A0 = np.asfortranarray(np.triu(rng.randn(w, w), -1)); B0 = np.asfortranarray(np.triu(rng.randn(w, w)) + 2.0 * np.eye(w))
+    Sm, Tm = A0.copy(order="F"), B0.copy(order="F")
+    Q = np.asfortranarray(np.eye(w)); Z = np.asfortranarray(np.eye(w))
+    ar = np.zeros(w); ai = np.zeros(w); be = np.zeros(w)
+    assert lib().sn_internal_gep_small_schur(w, P(Sm), w, P(Tm), w, P(Q), w, P(Z), w, P(ar), P(ai), P(be)) == 0
+    return Sm, Tm
+
+
+def _blocks(Sm):
+    """[(first row, size)] of the diagonal blocks of a quasi-triangular matrix"""
+    out, i, w = [], 0, Sm.shape[0]
+    while i < w:
+        bs = 2 if i + 1 < w and Sm[i + 1, i] != 0.0 else 1
+        out.append((i, bs)); i += bs
+    return out
+
+
+def _deflate(w, S0, T0, spike0, sub, thres, carried):
+    L = S.lib.load_test_hooks()
+    ip = C.POINTER(C.c_int)
+    L.sn_internal_gep_deflate_window.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [dp, C.c_double, C.c_double, C.c_int, ip]
+    L.sn_internal_gep_deflate_window.restype = C.c_int
+    Sm, Tm = S0.copy(order="F"), T0.copy(order="F")
+    Q = np.asfortranarray(np.eye(w)); Z = np.asfortranarray(np.eye(w))
+    spike = spike0.copy()
+    und = C.c_int(-1)
+    rc = L.sn_internal_gep_deflate_window(w, P(Sm), w, P(Tm), w, P(Q), w, P(Z), w, P(spike), sub, thres, carried,
+                                          C.byref(und))
+    return rc, Sm, Tm, Q, Z, spike, und.value
+
+
+@pytest.mark.parametrize("w,carried", [(40, 0), (64, 5), (96, 17)])
+def test_gep_deflate_window_on_a_diagonal_pencil_is_a_permutation(w, carried):
+    """On a pencil of two diagonal matrices every exchange is a signed permutation, so the outcome of
+    host::gep_deflate_window (the pencil twin of deflate_window; reference schur/cpu.c:638-1006 with B != NULL)
+    is known exactly: the carried rows first, in order, then the undeflatable rows in the order they were found
+    (from the bottom up), then the deflatable ones; the spike entries travel with their rows."""
+    rng = np.random.RandomState(w)
+    d = np.arange(1, w + 1) + rng.rand(w)
+    S0 = np.asfortranarray(np.diag(d)); T0 = np.asfortranarray(np.diag(1.0 + rng.rand(w)))
+    sub, thres = 1.0, 1e-8
+    big = np.zeros(w, dtype=bool)
+    big[rng.choice(w - carried, size=(w - carried) // 3, replace=False)] = True
+    big[w - carried:] = True
+    spike0 = np.where(big, 0.1 + rng.rand(w), 1e-12 * rng.rand(w))
+    rc, Sm, Tm, Q, Z, spike, und = _deflate(w, S0, T0, spike0, sub, thres, carried)
+    assert rc == 0 and und == int(big.sum())
+    check_gschur(S0, T0, Sm, Tm, Q, Z)
+    unchecked_big = [i for i in range(w - carried - 1, -1, -1) if big[i]]          # found from the bottom up
+    order = list(range(w - carried, w)) + unchecked_big
+    lam0 = d / np.diag(T0)
+    lam = np.diag(Sm) / np.diag(Tm)
+    assert np.allclose(lam[:und], lam0[order], rtol=1e-13)
+    assert np.allclose(np.abs(spike[:und]), np.abs(spike0[order]), rtol=1e-13)
+    assert np.all(np.abs(spike[und:]) < thres)
+
+
+@pytest.mark.parametrize("w,carried_blocks,seed", [(40, 0, 1), (64, 3, 2), (96, 5, 3)])
+def test_gep_deflate_window_of_the_blocked_aed(w, carried_blocks, seed):
+    """the same on a general window with 2 x 2 blocks: the decomposition stays intact, the spike follows the
+    left factor, the carried blocks sit at the top in their order, everything below `undeflated` is below the
+    threshold and no eigenvalue is lost"""
+    S0, T0 = _schur_window(w, seed)
+    blocks = _blocks(S0)
+    carried = sum(bs for _, bs in blocks[len(blocks) - carried_blocks:]) if carried_blocks else 0
+    rng = np.random.RandomState(100 + seed)
+    sub, thres = 1.0, 1e-8
+    spike0 = 1e-12 * rng.rand(w)
+    for i, bs in blocks[:3]:                                # the top three blocks cannot be deflated
+        spike0[i:i + bs] = 0.1 + rng.rand(bs)
+    if carried:
+        spike0[w - carried:] = 0.5
+    rc, Sm, Tm, Q, Z, spike, und = _deflate(w, S0, T0, spike0, sub, thres, carried)
+    assert rc == 0
+    check_gschur(S0, T0, Sm, Tm, Q, Z)
+    assert np.allclose(spike, spike0 @ Q, rtol=0, atol=1e-13)
+    assert carried <= und <= w
+    assert np.all(np.abs(spike[und:]) < thres)
+    if carried:
+        want = sl.eigvals(S0[w - carried:, w - carried:], T0[w - carried:, w - carried:])
+        got = sl.eigvals(Sm[:carried, :carried], Tm[:carried, :carried])
+        assert O.match_eigenvalues(np.asarray(got), np.asarray(want)) < 1e7
+    e0 = sl.eigvals(S0, T0); e1 = sl.eigvals(Sm, Tm)
+    assert O.match_eigenvalues(np.asarray(e1), np.asarray(e0)) < 1e7
+
+
+@pytest.mark.parametrize("w,seed", [(48, 4), (128, 5)])
+def test_gep_reorder_window_moves_the_marked_blocks_to_the_top(w, seed):
+    L = S.lib.load_test_hooks()
+    ip = C.POINTER(C.c_int)
+    L.sn_internal_gep_reorder_window.argtypes = [C.c_int] + [dp, C.c_int] * 4 + [ip, ip]
+    L.sn_internal_gep_reorder_window.restype = C.c_int
+    S0, T0 = _schur_window(w, seed)
+    blocks = _blocks(S0)
+    sel = np.zeros(w, dtype=np.int32)
+    marked = blocks[len(blocks) // 2:][::2]                 # every other block of the lower half
+    rows = 0
+    want = []
+    for i, bs in marked:
+        sel[i:i + bs] = 1; rows += bs
+        want.extend(sl.eigvals(S0[i:i + bs, i:i + bs], T0[i:i + bs, i:i + bs]))
+    Sm, Tm = S0.copy(order="F"), T0.copy(order="F")
+    Q = np.asfortranarray(np.eye(w)); Z = np.asfortranarray(np.eye(w))
+    failed = C.c_int(0)
+    placed = L.sn_internal_gep_reorder_window(w, P(Sm), w, P(Tm), w, P(Q), w, P(Z), w,
+                                              sel.ctypes.data_as(ip), C.byref(failed))
+    assert failed.value == 0 and placed == rows
+    check_gschur(S0, T0, Sm, Tm, Q, Z)
+    assert np.array_equal(sel, (np.arange(w) < rows).astype(np.int32))
+    got = sl.eigvals(Sm[:rows, :rows], Tm[:rows, :rows])
+    assert O.match_eigenvalues(np.asarray(got), np.asarray(want)) < 1e7
