@@ -312,9 +312,13 @@ def lapack_sample(n, cores):
     import numpy as np
     import scipy.linalg as sl
     from scipy.linalg import lapack
+    limiter = None
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+        # all the threads OpenBLAS will take (a launcher such as torch.distributed.run exports OMP_NUM_THREADS=1
+        # to its ranks: without this the N > 1 line would time a single-threaded LAPACK)
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=min(cores, 128), user_api="blas")
+        threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] + [1])
     except Exception:
         threads = cores
     import oracle as O
@@ -342,6 +346,8 @@ def lapack_sample(n, cores):
     if not err < 1e-10:
         raise RuntimeError(f"LAPACK comparator residual {err}")
     flops = hess_flops(n) + schur_flops(n)
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {"value": flops / (t2 - t0) / 1e9, "unit": "GFLOP/s", "cores": int(threads), "kind": "lapack",
             "sample": f"LAPACK (scipy OpenBLAS, {threads} threads of {cores} logical CPUs) on the LCG matrix "
                       f"at n={n}: dgehrd+dorghr {t1 - t0:.1f} s, dhseqr {t2 - t1:.1f} s; flop conventions "

@@ -135,7 +135,7 @@ struct UItem {
     int r;          // row of U, -1: no item
 };
 
-template <int DBG, bool UREG>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
+template <int DBG, bool UREG, int CHASE_THREADS = 1024>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
 __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
@@ -160,11 +160,17 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
     // 32 + 4w .. as well (96 rows = 24 groups of four): the hand-off of an entry from bulge i + 1 to bulge i
     // is a DPP shift inside a 16-lane row
     int const ui = tid & 15, usub = (tid >> 4) & 3, uw = tid >> 6;
-    UItem ua{0.0, 0.0, 0.0, -1}, ub{0.0, 0.0, 0.0, -1};
-    if (UREG) {
-        int const ra = 4 * uw + usub, rb = 32 + 4 * uw + usub;
-        if (ui < nb && ra < n) ua.r = ra;
-        if (ui < nb && uw >= 8 && rb < n) ub.r = rb;
+    constexpr int UNW = CHASE_THREADS / 64;                              // waves; 4 rows per wave and set
+    constexpr int USETS = (WS_MAX + 4 * UNW - 1) / (4 * UNW);            // 16 waves: 2 sets (the second on waves 8..15), 8 waves: 3
+    UItem uu[USETS];
+    #pragma unroll
+    for (int k = 0; k < USETS; k++) {
+        uu[k] = UItem{0.0, 0.0, 0.0, -1};
+        if (UREG) {
+            int const wk = (UNW == 16 && k == 1) ? uw - 8 : uw;          // (16 waves: rows 64..95 on waves 8..15, wave 0 carries the chain)
+            int const r = k * 4 * UNW + 4 * wk + usub;
+            if (ui < nb && wk >= 0 && r < n) uu[k].r = r;
+        }
     }
     int li[L_ITEMS], lc[L_ITEMS], ri[R_ITEMS], rr_[R_ITEMS];
     #pragma unroll
@@ -184,8 +190,10 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
     if (UREG) {
         // U = I: the entries of the bulges' first positions; the columns left of bulge 0's first position are final
         int const c0 = left + 3 * ui + 1;
-        ua.u0 = (ua.r == c0) ? 1.0 : 0.0; ua.u1 = (ua.r == c0 + 1) ? 1.0 : 0.0; ua.u2 = (ua.r == c0 + 2) ? 1.0 : 0.0;
-        ub.u0 = (ub.r == c0) ? 1.0 : 0.0; ub.u1 = (ub.r == c0 + 1) ? 1.0 : 0.0; ub.u2 = (ub.r == c0 + 2) ? 1.0 : 0.0;
+        #pragma unroll
+        for (int k = 0; k < USETS; k++) {
+            uu[k].u0 = (uu[k].r == c0) ? 1.0 : 0.0; uu[k].u1 = (uu[k].r == c0 + 1) ? 1.0 : 0.0; uu[k].u2 = (uu[k].r == c0 + 2) ? 1.0 : 0.0;
+        }
         for (int idx = tid; idx < (left + 1) * n; idx += CHASE_THREADS) {       // (left + 1 <= 0 at an introduction)
             int const r = idx % n, c = idx / n;
             Uo[c * WS_MAX + r] = (r == c) ? 1.0 : 0.0;
@@ -286,8 +294,8 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
             int const row0 = begin + 3 * ui + 1;
             bool const move = begin + 1 < right;
             #pragma unroll
-            for (int which = 0; which < 2; which++) {
-                UItem &it = which ? ub : ua;
+            for (int which = 0; which < USETS; which++) {
+                UItem &it = uu[which];
                 if (len != 0 && it.r >= 0) {
                     double const y2 = (len == 3) ? it.u2 : 0.0;
                     double const sum = rf.z * (it.u0 + rf.x * it.u1 + rf.y * y2);
@@ -316,8 +324,8 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
         int const last = max(left, right - 1);                 // `begin` of the last step (no step: the first positions)
         int const c0 = last + 3 * ui + 1;
         #pragma unroll
-        for (int which = 0; which < 2; which++) {
-            UItem const &it = which ? ub : ua;
+        for (int which = 0; which < USETS; which++) {
+            UItem const &it = uu[which];
             if (it.r < 0) continue;
             if (c0 >= 0 && c0 < n) Uo[c0 * WS_MAX + it.r] = it.u0;
             if (c0 + 1 >= 0 && c0 + 1 < n) Uo[(c0 + 1) * WS_MAX + it.r] = it.u1;
@@ -338,7 +346,16 @@ void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     __builtin_amdgcn_s_setprio(3);      // the latency-bound chain outranks the update kernels in instruction issue
     schur_chase_body<0, true>(step, H, ldH, Uout, sr, si);
 }
-// rounds 1-4: the accumulated factor in LDS beside the window (SN_SCHUR_CHASE_ULDS=1: comparisons, chase_bench.py)
+// 512 threads, at most 128 VGPRs: two waves per SIMD, so that the workgroup fits beside one update workgroup in
+// registers as well (update kernels: ~200 VGPRs, one wave per SIMD and workgroup) -- SN_SCHUR_CHASE_THREADS=512
+__global__ __launch_bounds__(512, 4)
+void schur_chase_512_kernel(SweepStep const step, double *__restrict__ H, int ldH,
+    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
+{
+    __builtin_amdgcn_s_setprio(3);
+    schur_chase_body<0, true, 512>(step, H, ldH, Uout, sr, si);
+}
+// rounds 1-4 and the default: the accumulated factor in LDS beside the window
 __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_ulds_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
@@ -571,6 +588,8 @@ struct SchurWorkspace {
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_ulds_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES_WU));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_512_kernel,
+                hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
             make_stream(&far, true, hi_prio);
@@ -1153,7 +1172,16 @@ struct Driver {
             // chain's first window would race with the finished chain's pending updates
             // (tests/test_schur_pipeline.py checks this rule on a model of the schedule).
             if (sw.issued > 0 && sw.last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
-            if (tuning().schur_chase_ulds)
+            // Default: the kernel of rounds 1-4 (window AND accumulated factor in LDS, 150 KB, 96 VGPRs).  Round 5
+            // built what round 4's anatomy asked for -- the factor out of LDS (registers + DPP hand-off, 75 KB) --
+            // and measured: alone 101 us against 98 us; a workgroup with 1024 threads then still cannot share a CU
+            // with an update workgroup because of REGISTERS (4 waves x 112 VGPRs per SIMD + 208 of the update
+            // kernel > 512), the 512-thread variant can (2 x 128 + 208) and takes 122 us alone; in situ the Schur leg
+            // is 1.67-1.72 s with all three (profiles/r5_chase_variants.txt).  SN_SCHUR_CHASE_UREG=1 [SN_SCHUR_CHASE_THREADS=512].
+            if (tuning().schur_chase_ureg && tuning().schur_chase_threads == 512)
+                hipLaunchKernelGGL(schur_chase_512_kernel, dim3(ntasks), dim3(512), CHASE_LDS_BYTES, s,
+                    step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
+            else if (!tuning().schur_chase_ureg)
                 hipLaunchKernelGGL(schur_chase_ulds_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES_WU, s,
                     step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
             else
@@ -1613,6 +1641,8 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
             case 4: go(schur_chase_dbg_kernel<4>); break;
             case 7: go(schur_chase_dbg_kernel<7>); break;
             case 8: go(schur_chase_ulds_kernel); break;
+            case 9: SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
+                    hipLaunchKernelGGL(schur_chase_512_kernel, dim3(chains), dim3(512), CHASE_LDS_BYTES, nullptr, step, H, ld, U, sr, si); break;
             default: go(schur_chase_kernel);
         }
         SN_HIP_CHECK(hipEventRecord(e1, nullptr));

@@ -23,7 +23,8 @@ struct Tuning {
     int schur_helpers = -1;         // SN_SCHUR_HELPERS: helper threads of the host window kernels (0 = none, -1 = five if the node has the cores)
     int schur_reuse = 0;            // SN_SCHUR_REUSE: fixed shift multiplicity (0 = adaptive)
     bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
-    bool schur_chase_ulds = false;  // SN_SCHUR_CHASE_ULDS: the chase kernel of rounds 1-4 (accumulated factor in LDS, 150 KB per window)
+    bool schur_chase_ureg = false;  // SN_SCHUR_CHASE_UREG: the chase kernel with the accumulated factor in registers (75 KB of LDS per window)
+    int schur_chase_threads = 1024; // SN_SCHUR_CHASE_THREADS: with UREG, 512 = half the waves and <= 128 VGPRs (fits beside an update workgroup)
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
     bool aed_profile = false;       // SN_AED_PROFILE
     bool schur_hs_prio = true;      // SN_SCHUR_HS_PRIO=0: lazy H stream at the priority of the lazy Q stream (else one level above)

@@ -32,7 +32,8 @@ Tuning const &tuning()
         t.schur_helpers = geti("SN_SCHUR_HELPERS", t.schur_helpers);
         t.schur_reuse = std::max(0, std::min(8, geti("SN_SCHUR_REUSE", 0)));
         t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
-        t.schur_chase_ulds = getb("SN_SCHUR_CHASE_ULDS");
+        t.schur_chase_ureg = getb("SN_SCHUR_CHASE_UREG");
+        t.schur_chase_threads = geti("SN_SCHUR_CHASE_THREADS", t.schur_chase_threads);
         t.schur_profile = getb("SN_SCHUR_PROFILE");
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);

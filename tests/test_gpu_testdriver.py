@@ -233,8 +233,6 @@ def test_ctest_schur_generalized_n4000(node, aed, parallel, decouple):
     whatever size was asked for (round 4 silently clamped the window to 768)."""
     import torch
     n = 4000
-    if not parallel and aed >= 2000 and decouple:
-        pytest.skip("the sequential 2000-row host AED is covered by the plain variant (minutes per run)")
     tH0, tR0, tQ0, tZ0, tA0, tB0 = gsweep_input(n, 3 if decouple else 0, 100 if decouple else 0)
     conf = node.schur_init_conf()
     conf.aed_window_size = aed
