@@ -24,6 +24,7 @@
 //               one lane per row, coalesced column loads; Q takes the row rotations the same way.
 //    The chain is what bounds the step (n^2/2 dependent rotations); everything else streams.
 #include "common.h"
+#include "tuning.h"
 #include <starneig/error.h>
 #include <algorithm>
 #include <chrono>
@@ -883,7 +884,10 @@ void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, doub
 
 } // namespace
 
-void hessenberg_triangular_release_workspace() { g_ht.release_buffers(); }
+void ht_two_stage_release_workspace();
+int ht_two_stage_device(hipStream_t s, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+    double *Z, int ldz, hipEvent_t between);
+void hessenberg_triangular_release_workspace() { g_ht.release_buffers(); ht_two_stage_release_workspace(); }
 
 // (dA, dB) general -> (H, T) upper Hessenberg / upper triangular with dQ <- dQ*U1, dZ <- dZ*U2
 // (dQ, dZ may be NULL).  stats (may be NULL): [0] total ms, [1] QR step ms, [2] rotation step ms,
@@ -917,8 +921,25 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht_chain_kernel<HG, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_DOUBLES(HG) * 8));
         attr_set = true;
     }
+    // The two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps: a developer switch
+    // (SN_HT_TWOSTAGE=1) -- DESIGN.md section 4d has the measurements and why the rotation path stays the default
+    int const two_stage = tuning().ht_two_stage && n >= 3;
+    if (two_stage) {
+        static hipEvent_t between = nullptr;
+        if (!between) SN_HIP_CHECK(hipEventCreate(&between));
+        int const rc2 = ht_two_stage_device(s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
+        if (rc2 != 0) return STARNEIG_GENERIC_ERROR;
+        if (stats) { stats[5] = 1.0; }
+        SN_HIP_CHECK(hipEventRecord(ws.e_side, s));
+        if (stats) {
+            SN_HIP_CHECK(hipEventSynchronize(ws.e_side));
+            float t1 = 0.f;
+            SN_HIP_CHECK(hipEventElapsedTime(&t1, ws.ev[1], between));
+            stats[6] = t1;          // stage 1 ms
+        }
+    }
     SN_HIP_CHECK(hipEventRecord(ws.e_side, s));
-    for (int j = 0; j + 2 < n; j++) {
+    for (int j = 0; j + 2 < n && !two_stage; j++) {
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));          // A, B, Z of the previous sweep complete
         ws.Rc = ws.Rc2[j & 1]; ws.Rs = ws.Rs2[j & 1];               // (Q and Z take the rotations of two sweeps per pass)
         ws.Cc = ws.Cc2[j % 3]; ws.Cs = ws.Cs2[j % 3];               // three buffers: the pass over Z that reads sweeps j-2, j-1 may still run
@@ -976,8 +997,8 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         rotations += 2.0 * (n - j - 2);
     }
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_side, 0));
-    if (dQ && n > 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));
-    if (dZ && n > 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0));
+    if (dQ && n > 2 && !two_stage) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[0], 0));
+    if (dZ && n > 2 && !two_stage) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_q[1], 0));
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, -1);
     int chain_err = 0;
     SN_HIP_CHECK(hipMemcpyAsync(&chain_err, ws.amax + 1, sizeof(int), hipMemcpyDeviceToHost, s));

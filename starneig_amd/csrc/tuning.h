@@ -39,6 +39,7 @@ struct Tuning {
     bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)
     bool gemm_nosplit = false;      // SN_GEMM_NOSPLIT: whole tiles in the last round of workgroups too
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
+    bool ht_two_stage = false;      // SN_HT_TWOSTAGE: Hessenberg-triangular reduction by the two-stage Householder path (ht_twostage.hip)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 0;              // SN_GEP_REUSE

@@ -443,7 +443,7 @@ def hessenberg_triangular_device(tA, tB, tQ, tZ, n=None):
         _dev_ptr(tQ), tQ.shape[1] if tQ is not None else 0,
         _dev_ptr(tZ), tZ.shape[1] if tZ is not None else 0, _stream_ptr(), st)
     return rc, {"total_ms": st[0], "qr_ms": st[1], "rotation_ms": st[2], "gemm_flops": st[3],
-                "rotations": st[4]}
+                "rotations": st[4], "two_stage": bool(st[5]), "stage1_ms": st[6]}
 
 
 def gep_schur_device(tH, tR, tQ, tZ, n=None, conf=None, eigenvalues=True):

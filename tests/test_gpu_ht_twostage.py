@@ -1,0 +1,54 @@
+"""GPU: the two-stage Householder reduction to Hessenberg-triangular form (csrc/ht_twostage.hip; developer switch
+SN_HT_TWOSTAGE=1, read once per process -> child processes).  Round 5 built it to replace the n^2/2 dependent
+column rotations of the rotation path and measured it SLOWER at n <= 8000: it is not the
+product path.  What is asserted here is that it is a correct, backward stable reduction -- exact structure, the
+reference's residual / orthogonality hooks -- also on a singular B, and that QZ accepts its output."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r"""
+import os, sys
+import numpy as np
+import torch
+torch.cuda.set_device(0); torch.zeros(1, device="cuda")
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import starneig_amd as S
+import oracle as O
+from helpers import to_device, to_host, torch_check_pencil
+S.node_init(4, 1, S.NO_MESSAGES)
+for n, singular in ((3, False), (66, False), (129, False), (200, True), (777, False), (2000, False)):
+    A0, B0 = O.random_fullpos_pair(n)
+    if singular:
+        B0[10, :] = 0.0; B0[:, 10] += 0.0      # a rank-deficient B: infinite eigenvalues
+    tA, tB = to_device(A0), to_device(B0)
+    tQ, tZ = to_device(O.identity(n)), to_device(O.identity(n))
+    rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+    assert rc == 0 and st["two_stage"], (rc, st)
+    H, T = to_host(tA), to_host(tB)
+    assert O.count_below_subdiagonal(H) == 0 and O.count_below_diagonal(T) == 0, n
+    ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
+    rb, _, _ = torch_check_pencil(tQ, tB, tZ, to_device(B0), n)
+    print(f"n={n}: residuals {ra:.1f} / {rb:.1f} u, orthogonality {oq:.1f} / {oz:.1f} u", flush=True)
+    assert max(ra, rb, oq, oz) < 500.0, (n, ra, rb, oq, oz)
+    if n == 777:
+        # QZ on the result: generalized Schur form, the eigenvalues of the original pencil
+        ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+        rc, ar, ai, be, st2 = S.gep_schur_device(tA, tB, tQ, tZ, n=n)
+        assert rc == 0 and O.check_gep_schur_form(to_host(tA), to_host(tB)) == 0
+        ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
+        assert max(ra, oq, oz) < 500.0
+S.node_finalize()
+print("OK")
+"""
+
+
+def test_two_stage_reduction_is_a_correct_hessenberg_triangular_reduction():
+    env = dict(os.environ, STARNEIG_AMD_TUNING="1", SN_HT_TWOSTAGE="1")
+    p = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
