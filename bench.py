@@ -214,7 +214,8 @@ def bench_ht(args):
     _, cb = S.check_pencil_device(tQ, tB, tZ, tB0, n=n)
     total = sum(times)
     cpu = lapack_ht_seconds(args.cpu_ht_n) if args.cpu_ht_n > 0 else None
-    chain_steps = st["rotations"] / 2
+    chain_steps = st["rotations"] / 2            # (0 on the two-stage path, SN_HT_TWOSTAGE=1: no rotation chain)
+    two_stage = bool(st.get("two_stage"))
     print(json.dumps({
         "metric": "GFLOP/s Hessenberg-triangular reduction, n=12000 general pencil, 1 MI355X",
         "value": args.steps * ht_flops(n) / total / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
@@ -227,9 +228,12 @@ def bench_ht(args):
                    "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
                    "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
                    "qr_step_s": st["qr_ms"] / 1e3, "rotation_step_s": st["rotation_ms"] / 1e3,
-                   "ns_per_chain_rotation": st["rotation_ms"] * 1e6 / max(chain_steps, 1)},
+                   "path": "two-stage Householder (stage 1 %.2f s, stage 2 %.2f s)" % (st["stage1_ms"] / 1e3, (st["rotation_ms"] - st["stage1_ms"]) / 1e3)
+                           if two_stage else "rotations (Moler-Stewart order, LDS-resident chain)",
+                   "ns_per_chain_rotation": None if two_stage else st["rotation_ms"] * 1e6 / max(chain_steps, 1)},
         # the step is bound by the dependent chain of n^2/2 column rotations, not by a roofline:
-        "roofline": {"bound": "latency", "achieved": st["rotation_ms"] * 1e6 / max(chain_steps, 1),
+        "roofline": None if two_stage else {
+                     "bound": "latency", "achieved": st["rotation_ms"] * 1e6 / max(chain_steps, 1),
                      "peak": 78.0, "unit": "ns per dependent rotation (peak = the bare arithmetic of one "
                      "rotation on one wave, scratch/ht_micro.hip)", "frac": 78.0 / (st["rotation_ms"] * 1e6 / max(chain_steps, 1)),
                      "traffic": None},
