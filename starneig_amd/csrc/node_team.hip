@@ -321,7 +321,6 @@ struct Team {
 // A heap singleton that is never destroyed: a process that leaves without starneig_node_finalize must not
 // run into the destructor of joinable threads (std::terminate) during static destruction.
 Team &team() { static Team *t = new Team; return *t; }
-#define g_team (team())
 
 struct RankComm { Team *team; int rank; double *buf[5]; hipStream_t s; };
 void team_allreduce_cb(void *ctx, int buffer, long offset, long count)
@@ -337,25 +336,25 @@ void team_broadcast_cb(void *ctx, int buffer, long offset, long count, int root)
 
 } // namespace
 
-int node_team_world() { return g_team.world; }
-bool node_team_uses_rccl() { return g_team.use_rccl; }
+int node_team_world() { return team().world; }
+bool node_team_uses_rccl() { return team().use_rccl; }
 
 // devices[r] = the device of rank r (the same device may appear more than once: virtual ranks)
 void node_team_start(int const *devices, int world)
 {
-    if (g_team.world) g_team.stop();
+    if (team().world) team().stop();
     if (world < 2) return;
     if (world > MAX_RANKS) world = MAX_RANKS;
-    g_team.start(std::vector<int>(devices, devices + world), getenv("STARNEIG_AMD_NO_RCCL") == nullptr);
+    team().start(std::vector<int>(devices, devices + world), getenv("STARNEIG_AMD_NO_RCCL") == nullptr);
 }
-void node_team_stop() { if (g_team.world) g_team.stop(); }
+void node_team_stop() { if (team().world) team().stop(); }
 
 // The reduction of the whole matrix on all ranks: A, Q are the caller's host arrays.  Every rank
 // uploads the matrix, the sharded reduction leaves the assembled H and Q on every rank, and every
 // rank brings a share of the columns back (N PCIe links instead of one).
 int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, int ldQ, int cores)
 {
-    Team &T = g_team;
+    Team &T = team();
     int const world = T.world;
     int const ld = (int)roundup(n, 16), ldp = hessenberg_panel_ld(n, panel_width);
     int const threads = std::max(1, cores / world);
@@ -445,7 +444,7 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
 int node_team_schur(int n, double *H, int ldH, double *Q, int ldQ, double *real, double *imag,
     SchurParams const &params, int cores)
 {
-    Team &T = g_team;
+    Team &T = team();
     int const world = T.world;
     int const ld = (int)roundup(n, 16);
     int const threads = std::max(1, cores / world);
