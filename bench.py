@@ -283,6 +283,25 @@ def cpu_baseline(n_lapack, n_port):
     return out
 
 
+def cpu_baseline_in_child(n_lapack):
+    """The LAPACK sample in a child process with a clean threading environment: a launcher such as
+    torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks, OpenBLAS sizes its thread pool from that when it
+    is loaded, and raising the count afterwards (threadpoolctl) crashes scipy's OpenBLAS 0.3.29 -- found by
+    running the N > 1 line, round 5.  The child never touches the GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "GOTO_NUM_THREADS")}
+    try:
+        proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cpu", "--cpu-n", str(n_lapack),
+                               "--cpu-port-n", "0"], capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"unit": "GFLOP/s", "kind": "lapack", "value": None, "error": f"child rc {proc.returncode}", "stderr_tail": proc.stderr[-400:]}
+    except Exception as e:
+        return {"unit": "GFLOP/s", "kind": "lapack", "value": None, "error": repr(e)[:300]}
+
+
 def port_sample(n_port, cores):
     import oracle as O
     import starneig_amd as S
@@ -318,12 +337,8 @@ def lapack_sample(n, cores):
     import numpy as np
     import scipy.linalg as sl
     from scipy.linalg import lapack
-    limiter = None
     try:
-        # all the threads OpenBLAS will take (a launcher such as torch.distributed.run exports OMP_NUM_THREADS=1
-        # to its ranks: without this the N > 1 line would time a single-threaded LAPACK)
-        from threadpoolctl import threadpool_info, threadpool_limits
-        limiter = threadpool_limits(limits=min(cores, 128), user_api="blas")
+        from threadpoolctl import threadpool_info
         threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] + [1])
     except Exception:
         threads = cores
@@ -352,8 +367,6 @@ def lapack_sample(n, cores):
     if not err < 1e-10:
         raise RuntimeError(f"LAPACK comparator residual {err}")
     flops = hess_flops(n) + schur_flops(n)
-    if limiter is not None:
-        limiter.restore_original_limits()
     return {"value": flops / (t2 - t0) / 1e9, "unit": "GFLOP/s", "cores": int(threads), "kind": "lapack",
             "sample": f"LAPACK (scipy OpenBLAS, {threads} threads of {cores} logical CPUs) on the LCG matrix "
                       f"at n={n}: dgehrd+dorghr {t1 - t0:.1f} s, dhseqr {t2 - t1:.1f} s; flop conventions "
@@ -476,7 +489,7 @@ def main():
                     help="1: also time ONE call of the host-array API (PCIe-inclusive), N=1 only")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded Hessenberg path even at N=1 (exercises the collectives)")
-    ap.add_argument("--workload", choices=["sep", "qz", "ht", "secondary"], default="sep",
+    ap.add_argument("--workload", choices=["sep", "qz", "ht", "secondary", "cpu"], default="sep",
                     help="sep = Hessenberg + Schur (the headline metric); qz = BASELINE config 5; "
                          "ht = Hessenberg-triangular reduction (the step before config 5)")
     ap.add_argument("--cpu-ht-n", type=int, default=1500,
@@ -496,6 +509,9 @@ def main():
         return bench_ht(args)
     if args.workload == "secondary":
         return bench_secondary(args)
+    if args.workload == "cpu":      # the CPU baseline alone (no GPU): what cpu_baseline_in_child runs
+        print(json.dumps(cpu_baseline(args.cpu_n, args.cpu_port_n)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -740,7 +756,7 @@ def main():
         # N > 1: the same baseline on rank 0's host cores -- after the process group is gone (no rank waits
         # inside a collective for it), the LAPACK sample only and a size smaller; the N = 1 line carries
         # the port as well
-        out["cpu_baseline"] = cpu_baseline(min(args.cpu_n, 3000), 0)
+        out["cpu_baseline"] = cpu_baseline_in_child(min(args.cpu_n, 3000))
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio
         import ctypes
