@@ -12,7 +12,13 @@
 // when the ranks sit on N distinct devices and librccl loads; otherwise -- ranks that share a device
 // (STARNEIG_AMD_VIRTUAL_GPUS, the mode the one-GPU test box uses) or no RCCL -- an in-process
 // exchange: the ranks meet at a barrier, read each other's device buffers (same device, or peers)
-// and sum them in rank order, so every rank gets the same bits.
+// and sum them in rank order, so every rank gets the same bits.  The per-column exchange of the Hessenberg
+// leg can also run on the device (peer stores + flags: HessExchange, common.h; the default for distinct devices
+// without RCCL, STARNEIG_AMD_TEAM_EXCHANGE=device elsewhere).
+// Ranks that share a device get a stream with a hardware queue of its own each: the in-order guarantee of plain
+// streams that the runtime multiplexes onto shared hardware queues did not survive several submitting threads
+// with oversubscribed queues (profiles/r5_sharded_reproducer.txt).
+// A rank that cannot allocate makes the call fail with an error code; the team object is never destroyed.
 #include "common.h"
 #include "tuning.h"
 #include <atomic>
