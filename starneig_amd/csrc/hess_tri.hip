@@ -885,7 +885,7 @@ void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, doub
 } // namespace
 
 void ht_two_stage_release_workspace();
-int ht_two_stage_device(hipStream_t s, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, hipEvent_t between);
 void hessenberg_triangular_release_workspace() { g_ht.release_buffers(); ht_two_stage_release_workspace(); }
 
@@ -927,7 +927,10 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
     if (two_stage) {
         static hipEvent_t between = nullptr;
         if (!between) SN_HIP_CHECK(hipEventCreate(&between));
-        int const rc2 = ht_two_stage_device(s, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
+        // (Q has taken the QR step's update on `s`: the stream of Q and Z starts behind it)
+        SN_HIP_CHECK(hipEventRecord(ws.e_scan, s));
+        SN_HIP_CHECK(hipStreamWaitEvent(ws.qstream, ws.e_scan, 0));
+        int const rc2 = ht_two_stage_device(s, ws.qstream, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
         if (rc2 != 0) return STARNEIG_GENERIC_ERROR;
         if (stats) { stats[5] = 1.0; }
         SN_HIP_CHECK(hipEventRecord(ws.e_side, s));

@@ -34,56 +34,95 @@ __device__ __forceinline__ double wsum64(double x)
     return x;
 }
 
-// Householder QR of the m x k matrix P in LDS (column-major, leading dimension ldp) by the whole workgroup (QT
-// threads): R in the upper triangle, the reflectors' vectors below the diagonal (unit diagonal implied), tau[0:k];
-// scl[c] = 1 (the vectors are scaled in place).  LAPACK dlarfg conventions.  Three workgroup barriers per column:
-// 2.7 us per column, 170 us for the 64 x 63 factorisation behind an opposite reflector, 270 us for a 128 x 64
-// panel with its T factor.  (A second version gave every column to ONE lane of ONE wave -- no barrier, no
-// reduction on the chain -- and was slower: a single wave hides no LDS latency; profiles/r5_ht_twostage_*.txt.)
-__device__ void wave_qr(double *P, int ldp, int m, int k, double *tau, double *scl)
+// Householder QR of the m x k matrix P in LDS (column-major, leading dimension ldp, k <= 64) by the whole workgroup
+// (QT = 1024 threads): R in the upper triangle, the UNSCALED reflector vectors x below the diagonal (v = scl[c] x,
+// v_c = 1), tau[0:k], scl[0:k].  LAPACK dlarfg conventions.
+//
+// History of this routine (profiles/r5_ht_twostage_*.txt): versions 1 and 3 kept the columns in LDS, one column per
+// WAVE at a time, with 64-lane shuffle sums (ds_bpermute, six dependent round trips a sum, up to five sums a wave
+// and step): 2.7 us per column whether with three barriers and a separate norm pass (1) or two barriers and the
+// norm carried along (3) -- 171 us for the 64 x 63 factorisation behind an opposite reflector, 231 us for a 128 x
+// 64 panel with its T factor.  Version 2 put every column on ONE lane of one wave (no barrier, no reduction):
+// slower still, a single wave hides no LDS latency.  Version 4 below: n = 4000 4.12 s -> 2.63 s, n = 8000
+// 13.9 s -> 10.2 s for the whole reduction.
+
+// 16-lane (DPP row) all-reduce of a double: four row rotations, no LDS crossbar round trip
+template <int CTRL>
+__device__ __forceinline__ double ht2_dpp(double x)
 {
-    __shared__ double red[2];
-    int const tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int const NW = blockDim.x / 64;
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += ht2_dpp<0x128>(x);   // row_ror:8
+    x += ht2_dpp<0x124>(x);   // row_ror:4
+    x += ht2_dpp<0x122>(x);   // row_ror:2
+    x += ht2_dpp<0x121>(x);   // row_ror:1
+    return x;
+}
+
+// Column j lives in the REGISTERS of the 16-lane group j of the workgroup (QT / 16 = 64 groups >= k; lane l holds rows l, l + 16, ...,
+// MR of them, m <= 16 MR), so every cross-lane sum is four DPP row rotations instead of six ds_bpermute round trips
+// and a step touches LDS only for the pivot column.  The group of column c + 1 forms that column's scalars and
+// publishes it (unscaled, with R above the diagonal) right after its own update: ONE barrier per column.
+template <int MR>
+__device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *scl)
+{
+    __shared__ double piv[2][2];
+    int const tid = threadIdx.x, l = tid & 15, g = tid >> 4;
     int const kref = min(m - 1, k);
+    double x[MR];
+    #pragma unroll
+    for (int r = 0; r < MR; r++) { int const i = l + 16 * r; x[r] = (g < k && i < m) ? P[g * ldp + i] : 0.0; }
+    auto publish = [&](int c) {           // by the group of column c, whose updates are complete
+        double s = 0.0, alpha = 0.0;
+        #pragma unroll
+        for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i > c) s += x[r] * x[r]; if (i == c) alpha = x[r]; }
+        s = row16_sum(s); alpha = row16_sum(alpha);
+        double t = 0.0, beta = alpha, scale = 0.0;
+        if (s != 0.0) { beta = -copysign(sqrt(alpha * alpha + s), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
+        #pragma unroll
+        for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i < m) P[c * ldp + i] = (i == c) ? beta : x[r]; }
+        if (l == 0) { tau[c] = t; scl[c] = scale; piv[c & 1][0] = t; piv[c & 1][1] = scale; }
+    };
+    if (g == 0 && kref > 0) publish(0);
+    __syncthreads();
     for (int c = 0; c < kref; c++) {
-        double *col = P + c * ldp;
-        if (wave == 0) {
-            double ss = 0.0;
-            for (int i = c + 1 + lane; i < m; i += 64) { double const x = col[i]; ss += x * x; }
-            ss = wsum64(ss);
-            if (lane == 0) {
-                double const alpha = col[c];
-                double t = 0.0, beta = alpha, scale = 0.0;
-                if (ss != 0.0) {
-                    beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-                    t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta);
+        double const t = piv[c & 1][0], scale = piv[c & 1][1];
+        if (g > c && g < k) {
+            if (t != 0.0) {
+                double const *col = P + c * ldp;
+                double pc[MR], w = 0.0, xc = 0.0;
+                #pragma unroll
+                for (int r = 0; r < MR; r++) {
+                    int const i = l + 16 * r;
+                    pc[r] = (i > c && i < m) ? col[i] : 0.0;
+                    w += pc[r] * x[r];
+                    if (i == c) xc = x[r];
                 }
-                tau[c] = t; scl[c] = 1.0; red[0] = scale; red[1] = beta;
+                w = row16_sum(w); xc = row16_sum(xc);
+                w = (w * scale + xc) * t;
+                double const wsc = w * scale;
+                #pragma unroll
+                for (int r = 0; r < MR; r++) { int const i = l + 16 * r; x[r] -= wsc * pc[r]; if (i == c) x[r] -= w; }
             }
+            if (g == c + 1 && c + 1 < kref) publish(c + 1);
         }
         __syncthreads();
-        double const scale = red[0], t = tau[c];
-        for (int i = c + 1 + tid; i < m; i += blockDim.x) col[i] *= scale;
-        if (tid == 0) col[c] = red[1];
-        __syncthreads();
-        if (t != 0.0)
-            for (int j = c + 1 + wave; j < k; j += NW) {
-                double *cj = P + j * ldp;
-                double w = 0.0;
-                for (int i = c + 1 + lane; i < m; i += 64) w += col[i] * cj[i];
-                w = (wsum64(w) + cj[c]) * t;
-                for (int i = c + 1 + lane; i < m; i += 64) cj[i] -= w * col[i];
-                if (lane == 0) cj[c] -= w;
-            }
-        __syncthreads();
     }
-    for (int c = kref + tid; c < k; c += blockDim.x) { tau[c] = 0.0; scl[c] = 1.0; }
+    if (g >= kref && g < k) {
+        #pragma unroll
+        for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i < m) P[g * ldp + i] = x[r]; }
+        if (l == 0) { tau[g] = 0.0; scl[g] = 0.0; }
+    }
     __syncthreads();
 }
 
 // T (k x k, upper triangular, leading dimension ldt, in LDS) of the compact-WY form H_0 H_1 ... H_{k-1} =
-// I - V T V^T from the panel wave_qr left (v_c = [0 .. 0, 1, scl[c] P(c+1:m, c)]; LAPACK dlarft, forward /
+// I - V T V^T from the panel group_qr left (v_c = [0 .. 0, 1, scl[c] P(c+1:m, c)]; LAPACK dlarft, forward /
 // columnwise).  All threads of the workgroup: the Gram matrix entry by entry, then every row of T by its own
 // thread (row i of T depends on row i alone).  G: k x k scratch in LDS.
 __device__ void lds_tfactor(double const *P, int ldp, int m, int k, double const *tau, double const *scl,
@@ -122,7 +161,7 @@ __global__ __launch_bounds__(QT) void ht2_panel_qr_kernel(double *__restrict__ X
     int const tid = threadIdx.x;
     for (int e = tid; e < m * nb; e += QT) { int const i = e % m, j = e / m; P[j * LDP + i] = X[(size_t)j * ldx + i]; }
     __syncthreads();
-    wave_qr(P, LDP, m, nb, tau, scl);
+    group_qr<2 * R2 / 16>(P, LDP, m, nb, tau, scl);
     lds_tfactor(P, LDP, m, nb, tau, scl, Tl, R2, G);
     for (int e = tid; e < m * nb; e += QT) {
         int const i = e % m, j = e / m;
@@ -148,7 +187,7 @@ __global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int
         P[b * LDP + a] = Mb[(size_t)(m - 1 - a) * ldb + (mb - 1 - b)];
     }
     __syncthreads();
-    wave_qr(P, LDP, m, mb, tau, scl);
+    group_qr<2 * R2 / 16>(P, LDP, m, mb, tau, scl);
     lds_tfactor(P, LDP, m, mb, tau, scl, Tl, R2, G);
     for (int e = tid; e < m * mb; e += QT) {
         int const a = e % m, b = e / m;
@@ -227,12 +266,11 @@ __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__
     }
 }
 
-// X(rb:re, p:p1) <- X (I - tau v v^T): one thread per row, the row's entries in registers.
-//   side 0 (after the left build): X = Q, all rows.
-//   side 1 (after the right build): z = 0: B rows [0, p1) (and the first column of the block cleaned),
-//                                   z = 1: A rows [0, min(p1 + r, n)), z = 2: Z all rows.
-__global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, int side, double *__restrict__ X0, int ld0,
-    double *__restrict__ X1, int ld1, double *__restrict__ X2, int ld2, int nrows_q,
+// X(0:rows, p:p1) <- X (I - tau v v^T) for up to three targets: one thread per row, the row's entries in
+// registers.  kind 0: all nrows rows (Q, Z); kind 1: rows [0, p1) and the first column of the block cleaned below
+// its diagonal entry (B after the opposite reflector); kind 2: rows [0, min(p1 + r, n)) (A).
+struct RightTargets { double *X[3]; int ld[3]; int kind[3]; };
+__global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTargets tg, int nrows,
     double const *__restrict__ RV, double const *__restrict__ RT)
 {
     __shared__ double s_v[R2];
@@ -241,12 +279,9 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, int side,
     if (!step_of(w, k, p, p1, c0)) return;
     double const tau = RT[k];
     int const len = p1 - p, z = blockIdx.z;
-    double *X = z == 0 ? X0 : (z == 1 ? X1 : X2);
-    int const ld = z == 0 ? ld0 : (z == 1 ? ld1 : ld2);
-    if (X == nullptr) return;
-    int rows;
-    if (side == 0) rows = nrows_q;
-    else rows = z == 0 ? p1 : (z == 1 ? min(p1 + R2, w.n) : nrows_q);
+    double *X = tg.X[z];
+    int const ld = tg.ld[z], kind = tg.kind[z];
+    int const rows = kind == 0 ? nrows : (kind == 1 ? p1 : min(p1 + R2, w.n));
     int const row = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256 >= rows) return;
     if (threadIdx.x < R2) s_v[threadIdx.x] = threadIdx.x < len ? RV[k * R2 + threadIdx.x] : 0.0;
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, int side,
         #pragma unroll
         for (int q = 0; q < R2; q++) if (q < len) x[(size_t)q * ld] = y[q] - d * s_v[q];
     }
-    if (side == 1 && z == 0 && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
+    if (kind == 1 && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
 }
 
 // the opposite reflector of every step: x orthogonal to rows 1 .. len-1 of M = B(p:p1, p:p1) (QR of those rows,
@@ -282,41 +317,70 @@ __global__ __launch_bounds__(QT) void ht2_geng_kernel(Wave2 w, double const *__r
         P[b * LQ + a] = B[(size_t)(p + a) * ldb + p + b + 1];
     }
     __syncthreads();
-    wave_qr(P, LQ, len, kq, tau, scl);
-    if (tid < 64) {
-        // e = H_0 ... H_{kq-1} e_{len-1}, one entry per lane; then the reflector from x = e (dlarfg)
-        int const lane = tid;
-        double ev = (lane == len - 1) ? 1.0 : 0.0;
+    group_qr<R2 / 16>(P, LQ, len, kq, tau, scl);
+    if (tid < 16) {
+        // e = H_0 ... H_{kq-1} e_{len-1}, four entries per lane of ONE 16-lane group (DPP sums); then the
+        // reflector from x = e (dlarfg)
+        int const l = tid;
+        double ev[4], vi[4];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) ev[r] = (l + 16 * r == len - 1) ? 1.0 : 0.0;
         for (int c = kq - 1; c >= 0; c--) {
             double const t = tau[c];
             if (t == 0.0) continue;
-            double const vi = (lane > c && lane < len) ? scl[c] * P[c * LQ + lane] : (lane == c ? 1.0 : 0.0);
-            double const d = wsum64(vi * ev) * t;
-            ev -= d * vi;
+            double const sc = scl[c];
+            double d = 0.0;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int const i = l + 16 * r;
+                vi[r] = (i > c && i < len) ? sc * P[c * LQ + i] : (i == c ? 1.0 : 0.0);
+                d += vi[r] * ev[r];
+            }
+            d = row16_sum(d) * t;
+            #pragma unroll
+            for (int r = 0; r < 4; r++) ev[r] -= d * vi[r];
         }
-        double const x = lane < len ? ev : 0.0;
-        double const ss = wsum64(lane >= 1 ? x * x : 0.0);
-        double const alpha = __shfl(x, 0);
+        double ss = 0.0, alpha = 0.0;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int const i = l + 16 * r;
+            if (i >= len) ev[r] = 0.0;
+            if (i >= 1) ss += ev[r] * ev[r]; else alpha = ev[r];
+        }
+        ss = row16_sum(ss); alpha = row16_sum(alpha);
         double t = 0.0, scale = 0.0;
         if (ss != 0.0) { double const beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
-        GV[k * R2 + lane] = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
-        if (lane == 0) GT[k] = t;
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int const i = l + 16 * r;
+            GV[k * R2 + i] = i == 0 ? 1.0 : (i < len ? ev[r] * scale : 0.0);
+        }
+        if (l == 0) GT[k] = t;
     }
 }
 constexpr int GENG_LDS_BYTES = (R2 * (R2 + 1) + 3 * R2 + 16) * 8;
 
+constexpr int RING = 8;             // factor slots in flight between the critical stream and the stream of Q and Z
 struct Ht2Workspace {
     int n = 0;
-    double *V = nullptr, *T = nullptr, *W1 = nullptr, *W2 = nullptr;
-    double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;
+    double *V = nullptr, *T = nullptr;              // stage 1: RING slots of (2r x r) and (r x r)
+    double *W1 = nullptr, *W2 = nullptr, *W1q = nullptr, *W2q = nullptr;   // GEMM scratch of the two streams
+    double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: RING slots of maxk reflectors
     int maxk = 0;
     bool attr = false;
+    hipEvent_t ready[RING] = {}, ready2[RING] = {}, used[RING] = {}, tail = nullptr;
     void ensure(int n_)
     {
         if (!attr) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_geng_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GENG_LDS_BYTES));
+            for (int k = 0; k < RING; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&ready2[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&used[k], hipEventDisableTiming));
+            }
+            SN_HIP_CHECK(hipEventCreateWithFlags(&tail, hipEventDisableTiming));
             attr = true;
         }
         if (n_ <= n) return;
@@ -324,13 +388,13 @@ struct Ht2Workspace {
         n = n_;
         maxk = n / (3 * R2 - 1) + 4;
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
-        alloc(V, (size_t)2 * R2 * R2); alloc(T, (size_t)R2 * R2);
-        alloc(W1, (size_t)R2 * n); alloc(W2, (size_t)R2 * n);
-        alloc(HV, (size_t)maxk * R2); alloc(HT, maxk); alloc(GV, (size_t)maxk * R2); alloc(GT, maxk);
+        alloc(V, (size_t)RING * 2 * R2 * R2); alloc(T, (size_t)RING * R2 * R2);
+        alloc(W1, (size_t)R2 * n); alloc(W2, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n); alloc(W2q, (size_t)R2 * n);
+        alloc(HV, (size_t)RING * maxk * R2); alloc(HT, (size_t)RING * maxk); alloc(GV, (size_t)RING * maxk * R2); alloc(GT, (size_t)RING * maxk);
     }
     void release()
     {
-        double **all[] = {&V, &T, &W1, &W2, &HV, &HT, &GV, &GT};
+        double **all[] = {&V, &T, &W1, &W2, &W1q, &W2q, &HV, &HT, &GV, &GT};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
@@ -338,53 +402,77 @@ struct Ht2Workspace {
 Ht2Workspace g_ht2;
 
 // X (m x ncols) <- (I - V T V^T)^T X
-void wy_left(hipStream_t s, Ht2Workspace &ws, int m, int k, int ncols, double *X, int ldx)
+void wy_left(hipStream_t s, double const *V, double const *T, double *W1, double *W2, int m, int k, int ncols, double *X, int ldx)
 {
     if (ncols <= 0 || k <= 0) return;
-    dgemm(s, 'T', 'N', k, ncols, m, 1.0, ws.V, 2 * R2, X, ldx, 0.0, ws.W1, R2);
-    dgemm(s, 'T', 'N', k, ncols, k, 1.0, ws.T, k, ws.W1, R2, 0.0, ws.W2, R2);
-    dgemm(s, 'N', 'N', m, ncols, k, -1.0, ws.V, 2 * R2, ws.W2, R2, 1.0, X, ldx);
+    dgemm(s, 'T', 'N', k, ncols, m, 1.0, V, 2 * R2, X, ldx, 0.0, W1, R2);
+    dgemm(s, 'T', 'N', k, ncols, k, 1.0, T, k, W1, R2, 0.0, W2, R2);
+    dgemm(s, 'N', 'N', m, ncols, k, -1.0, V, 2 * R2, W2, R2, 1.0, X, ldx);
 }
 // X (nrows x m) <- X (I - V T V^T)
-void wy_right(hipStream_t s, Ht2Workspace &ws, int nrows, int m, int k, double *X, int ldx)
+void wy_right(hipStream_t s, double const *V, double const *T, double *W1, double *W2, int nrows, int m, int k, double *X, int ldx)
 {
     if (nrows <= 0 || k <= 0) return;
-    dgemm(s, 'N', 'N', nrows, k, m, 1.0, X, ldx, ws.V, 2 * R2, 0.0, ws.W1, nrows);
-    dgemm(s, 'N', 'N', nrows, k, k, 1.0, ws.W1, nrows, ws.T, k, 0.0, ws.W2, nrows);
-    dgemm(s, 'N', 'T', nrows, m, k, -1.0, ws.W2, nrows, ws.V, 2 * R2, 1.0, X, ldx);
+    dgemm(s, 'N', 'N', nrows, k, m, 1.0, X, ldx, V, 2 * R2, 0.0, W1, nrows);
+    dgemm(s, 'N', 'N', nrows, k, k, 1.0, W1, nrows, T, k, 0.0, W2, nrows);
+    dgemm(s, 'N', 'T', nrows, m, k, -1.0, W2, nrows, V, 2 * R2, 1.0, X, ldx);
 }
 
 } // namespace
 
 void ht_two_stage_release_workspace() { g_ht2.release(); }
 
-// (A, B), B upper triangular -> Hessenberg-triangular, Q <- Q U1, Z <- Z U2 (Q, Z may be NULL).  Everything on `s`.
-// ms[0], ms[1] (may be NULL): set by the caller from events around the two stages.
-int ht_two_stage_device(hipStream_t s, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
+// (A, B), B upper triangular -> Hessenberg-triangular, Q <- Q U1, Z <- Z U2 (Q, Z may be NULL).  The reduction
+// of A and B runs on `s`; Q and Z -- nothing reads them before the end -- take their transformations on `sq`
+// (may be `s` itself) from a ring of factor slots, beside the next factorisations.
+int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, hipEvent_t between)
 {
     Ht2Workspace &ws = g_ht2;
     ws.ensure(n);
     int const r = R2;
+    if (!sq) sq = s;
+    long slot_count = 0;
+    // a factor slot: wait until `sq` has used its previous content, fill it on `s`, hand it to `sq`
+    auto slot_begin = [&]() {
+        int const k = (int)(slot_count % RING);
+        if (slot_count >= RING && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.used[k], 0));
+        return k;
+    };
+    auto slot_ready = [&](int k, hipEvent_t *ev) {
+        if (sq == s) return;
+        SN_HIP_CHECK(hipEventRecord(ev[k], s));
+        SN_HIP_CHECK(hipStreamWaitEvent(sq, ev[k], 0));
+    };
+    auto slot_end = [&](int k) {
+        if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.used[k], sq));
+        slot_count++;
+    };
     // ---- stage 1 -----------------------------------------------------------------------------------------------
     for (int jc = 0; jc < n - r - 1; jc += r) {
         int const nb = std::min(r, n - jc), top = jc + r;
         std::vector<int> starts;
         for (int i = top; i < n; i += r) starts.push_back(i);
         auto left_step = [&](int i0, int i1) {
-            int const m = i1 - i0, k = nb;
-            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, ws.V, 2 * r, ws.T);
-            wy_left(s, ws, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
-            wy_left(s, ws, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
-            if (Q) wy_right(s, ws, n, m, k, Q + (size_t)i0 * ldq, ldq);
+            int const m = i1 - i0, k = nb, sl = slot_begin();
+            double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
+            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, V, 2 * r, T);
+            slot_ready(sl, ws.ready);
+            wy_left(s, V, T, ws.W1, ws.W2, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
+            wy_left(s, V, T, ws.W1, ws.W2, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
+            if (Q) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, k, Q + (size_t)i0 * ldq, ldq);
+            slot_end(sl);
         };
         auto right_step = [&](int i0, int i1, int mb) {
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
-            int const m = i1 - i0;
-            hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, ws.V, 2 * r, ws.T);
-            wy_right(s, ws, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
-            wy_right(s, ws, n, m, mb, A + (size_t)i0 * lda, lda);
-            if (Z) wy_right(s, ws, n, m, mb, Z + (size_t)i0 * ldz, ldz);
+            int const m = i1 - i0, sl = slot_begin();
+            double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
+            hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, 2 * r, T);
+            slot_ready(sl, ws.ready);
+            wy_right(s, V, T, ws.W1, ws.W2, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
+            wy_right(s, V, T, ws.W1, ws.W2, n, m, mb, A + (size_t)i0 * lda, lda);
+            if (Z) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
+            slot_end(sl);
         };
         int const K = (int)starts.size();
         for (int k = K - 1; k >= 1; k--) {
@@ -408,14 +496,27 @@ int ht_two_stage_device(hipStream_t s, int n, double *A, int lda, double *B, int
         int const count = jhi - jlo + 1;
         if (count > ws.maxk) return -1;
         Wave2 const w{n, tau_idx, jlo, count};
-        hipLaunchKernelGGL(ht2_genh_kernel, dim3(count), dim3(64), 0, s, w, A, lda, ws.HV, ws.HT);
-        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, 256), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT);
+        int const sl = slot_begin();
+        double *HV = ws.HV + (size_t)sl * ws.maxk * R2, *HT = ws.HT + (size_t)sl * ws.maxk;
+        double *GV = ws.GV + (size_t)sl * ws.maxk * R2, *GT = ws.GT + (size_t)sl * ws.maxk;
+        hipLaunchKernelGGL(ht2_genh_kernel, dim3(count), dim3(64), 0, s, w, A, lda, HV, HT);
+        slot_ready(sl, ws.ready);
+        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, 256), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, HV, HT);
         if (Q)
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 1), dim3(256), 0, s, w, 0, Q, ldq,
-                (double *)nullptr, 0, (double *)nullptr, 0, n, ws.HV, ws.HT);
-        hipLaunchKernelGGL(ht2_geng_kernel, dim3(count), dim3(QT), GENG_LDS_BYTES, s, w, B, ldb, ws.GV, ws.GT);
-        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, Z ? 3 : 2), dim3(256), 0, s, w, 1, B, ldb,
-            A, lda, Z, ldz, n, ws.GV, ws.GT);
+            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 1), dim3(256), 0, sq, w,
+                RightTargets{{Q, nullptr, nullptr}, {ldq, 0, 0}, {0, 0, 0}}, n, HV, HT);
+        hipLaunchKernelGGL(ht2_geng_kernel, dim3(count), dim3(QT), GENG_LDS_BYTES, s, w, B, ldb, GV, GT);
+        slot_ready(sl, ws.ready2);
+        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 2), dim3(256), 0, s, w,
+            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, GV, GT);
+        if (Z)
+            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 1), dim3(256), 0, sq, w,
+                RightTargets{{Z, nullptr, nullptr}, {ldz, 0, 0}, {0, 0, 0}}, n, GV, GT);
+        slot_end(sl);
+    }
+    if (sq != s) {
+        SN_HIP_CHECK(hipEventRecord(ws.tail, sq));
+        SN_HIP_CHECK(hipStreamWaitEvent(s, ws.tail, 0));
     }
     return 0;
 }
