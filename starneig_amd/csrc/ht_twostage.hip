@@ -215,27 +215,10 @@ __device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, 
     return true;
 }
 
-// left reflector of every step of the wavefront: v (HV[k][0:64], v[0] = 1), tau (HT[k]); the column is reduced
-__global__ __launch_bounds__(64) void ht2_genh_kernel(Wave2 w, double *__restrict__ A, int lda,
-    double *__restrict__ HV, double *__restrict__ HT)
-{
-    int const k = blockIdx.x, lane = threadIdx.x;
-    int p, p1, c0;
-    if (!step_of(w, k, p, p1, c0)) { if (lane == 0) HT[k] = 0.0; HV[k * R2 + lane] = 0.0; return; }
-    int const len = p1 - p;
-    double *col = A + (size_t)c0 * lda + p;
-    double const x = lane < len ? col[lane] : 0.0;
-    double const ss = wsum64(lane >= 1 ? x * x : 0.0);
-    double const alpha = __shfl(x, 0);
-    double t = 0.0, beta = alpha, scale = 0.0;
-    if (ss != 0.0) { beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
-    HV[k * R2 + lane] = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
-    if (lane == 0) HT[k] = t;
-    if (lane < len) col[lane] = lane == 0 ? beta : 0.0;
-}
-
 // X(p:p1, cb:n) <- (I - tau v v^T) X for X = A (z = 0, cb = c0 + 1) and X = B (z = 1, cb = p): 16 lanes per
-// column, four rows each; blockIdx.x: chunk of 256 columns, blockIdx.y: step
+// column, four rows each (DPP sums); blockIdx.x: chunk of LEFT_CHUNK columns, four per 16-lane group, all in
+// flight together; blockIdx.y: step
+constexpr int LEFT_CHUNK = 64;
 __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__restrict__ A, int lda,
     double *__restrict__ B, int ldb, double const *__restrict__ HV, double const *__restrict__ HT)
 {
@@ -247,33 +230,43 @@ __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__
     bool const isB = blockIdx.z == 1;
     double *X = isB ? B : A;
     int const ld = isB ? ldb : lda, cb = isB ? p : c0 + 1, len = p1 - p;
+    int const cbeg = cb + blockIdx.x * LEFT_CHUNK;
+    if (cbeg >= w.n) return;
     int const tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;            // 16 column groups per block
     int const r0 = 4 * l16;
     double v[4];
     #pragma unroll
     for (int q = 0; q < 4; q++) v[q] = (r0 + q < len) ? HV[k * R2 + r0 + q] : 0.0;
-    int const cbeg = cb + blockIdx.x * 256;
-    for (int c = cbeg + grp; c < min(cbeg + 256, w.n); c += 16) {
+    constexpr int NC = LEFT_CHUNK / 16;
+    double y[NC][4], d[NC];
+    #pragma unroll
+    for (int u = 0; u < NC; u++) {
+        int const c = cbeg + grp + 16 * u;
+        double const *x = X + (size_t)c * ld + p + r0;
+        d[u] = 0.0;
+        #pragma unroll
+        for (int q = 0; q < 4; q++) { y[u][q] = (c < w.n && r0 + q < len) ? x[q] : 0.0; d[u] += v[q] * y[u][q]; }
+    }
+    #pragma unroll
+    for (int u = 0; u < NC; u++) d[u] = row16_sum(d[u]) * tau;
+    #pragma unroll
+    for (int u = 0; u < NC; u++) {
+        int const c = cbeg + grp + 16 * u;
         double *x = X + (size_t)c * ld + p + r0;
-        double y[4], d = 0.0;
         #pragma unroll
-        for (int q = 0; q < 4; q++) { y[q] = (r0 + q < len) ? x[q] : 0.0; d += v[q] * y[q]; }
-        // sum over the 16 lanes of the column
-        d += __shfl_xor(d, 8, 16); d += __shfl_xor(d, 4, 16); d += __shfl_xor(d, 2, 16); d += __shfl_xor(d, 1, 16);
-        d *= tau;
-        #pragma unroll
-        for (int q = 0; q < 4; q++) if (r0 + q < len) x[q] = y[q] - d * v[q];
+        for (int q = 0; q < 4; q++) if (c < w.n && r0 + q < len) x[q] = y[u][q] - d[u] * v[q];
     }
 }
 
-// X(0:rows, p:p1) <- X (I - tau v v^T) for up to three targets: one thread per row, the row's entries in
-// registers.  kind 0: all nrows rows (Q, Z); kind 1: rows [0, p1) and the first column of the block cleaned below
-// its diagonal entry (B after the opposite reflector); kind 2: rows [0, min(p1 + r, n)) (A).
+// X(0:rows, p:p1) <- X (I - tau v v^T) for up to three targets: a workgroup takes 64 rows, wave q of its four the
+// columns 16 q .. 16 q + 15 of the block (lane = row: every load is 512 contiguous bytes), the partial row sums
+// meet in LDS.  kind 0: all nrows rows (Q, Z); kind 1: rows [0, p1) and the first column of the block cleaned
+// below its diagonal entry (B after the opposite reflector); kind 2: rows [0, min(p1 + r, n)) (A).
 struct RightTargets { double *X[3]; int ld[3]; int kind[3]; };
 __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTargets tg, int nrows,
     double const *__restrict__ RV, double const *__restrict__ RT)
 {
-    __shared__ double s_v[R2];
+    __shared__ double s_d[4][64];
     int const k = blockIdx.y;
     int p, p1, c0;
     if (!step_of(w, k, p, p1, c0)) return;
@@ -282,39 +275,79 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
     double *X = tg.X[z];
     int const ld = tg.ld[z], kind = tg.kind[z];
     int const rows = kind == 0 ? nrows : (kind == 1 ? p1 : min(p1 + R2, w.n));
-    int const row = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= rows) return;
-    if (threadIdx.x < R2) s_v[threadIdx.x] = threadIdx.x < len ? RV[k * R2 + threadIdx.x] : 0.0;
-    __syncthreads();
-    if (row >= rows) return;
-    double *x = X + (size_t)p * ld + row;
+    if (blockIdx.x * 64 >= rows) return;
+    int const lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    int const row = blockIdx.x * 64 + lane, q0 = 16 * part;
+    bool const live = row < rows;
+    double *x = X + (size_t)(p + q0) * ld + row;
     if (tau != 0.0) {
-        double y[R2], d = 0.0;
+        double y[16], v[16], d = 0.0;
         #pragma unroll
-        for (int q = 0; q < R2; q++) { y[q] = q < len ? x[(size_t)q * ld] : 0.0; d += y[q] * s_v[q]; }
-        d *= tau;
+        for (int q = 0; q < 16; q++) {
+            v[q] = q0 + q < len ? RV[k * R2 + q0 + q] : 0.0;
+            y[q] = (live && q0 + q < len) ? x[(size_t)q * ld] : 0.0;
+            d += y[q] * v[q];
+        }
+        s_d[part][lane] = d;
+        __syncthreads();
+        d = ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane])) * tau;
         #pragma unroll
-        for (int q = 0; q < R2; q++) if (q < len) x[(size_t)q * ld] = y[q] - d * s_v[q];
+        for (int q = 0; q < 16; q++) if (live && q0 + q < len) x[(size_t)q * ld] = y[q] - d * v[q];
     }
-    if (kind == 1 && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
+    if (kind == 1 && part == 0 && live && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
 }
 
-// the opposite reflector of every step: x orthogonal to rows 1 .. len-1 of M = B(p:p1, p:p1) (QR of those rows,
-// transposed, in LDS; x = the last column of the full Q), then the reflector G = I - tz w w^T with G e_1 = +-x
-__global__ __launch_bounds__(QT) void ht2_geng_kernel(Wave2 w, double const *__restrict__ B, int ldb,
-    double *__restrict__ GV, double *__restrict__ GT)
+// Both reflectors of every step of the wavefront, one workgroup per step.  Wave 0: the left reflector H = I - th v
+// v^T from A's overhanging column (v -> HV[k], th -> HT[k]; the column is reduced in place).  All: the block
+// Bb = B(p:p1, p:p1) as it stands BEFORE H (the wide left application of this wavefront follows this kernel and
+// does not have to precede it), M = H Bb formed in LDS, then the opposite reflector: x orthogonal to rows 1 ..
+// len-1 of M (QR of those rows, transposed; x = the last column of the full Q) and G = I - tz w w^T with
+// G e_1 = +-x (w -> GV[k], tz -> GT[k]).  Bb is a full block (the bulge of B travels with the sweep; a step
+// restores its first column only), so there is no triangular short cut to x.
+__global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
+    double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int LQ = R2 + 1;
-    double *P = lds, *tau = P + R2 * LQ, *scl = tau + R2;
+    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
+    __shared__ double s_th;
     int const k = blockIdx.x, tid = threadIdx.x;
     int p, p1, c0;
-    if (!step_of(w, k, p, p1, c0)) { if (tid == 0) GT[k] = 0.0; if (tid < R2) GV[k * R2 + tid] = 0.0; return; }
+    if (!step_of(w, k, p, p1, c0)) {
+        if (tid == 0) { GT[k] = 0.0; HT[k] = 0.0; }
+        if (tid < R2) { GV[k * R2 + tid] = 0.0; HV[k * R2 + tid] = 0.0; }
+        return;
+    }
     int const len = p1 - p, kq = len - 1;
-    // P(a, b) = M(b + 1, a): len rows, len - 1 columns
+    if (tid < 64) {
+        int const lane = tid;
+        double *col = A + (size_t)c0 * lda + p;
+        double const x = lane < len ? col[lane] : 0.0;
+        double const ss = wsum64(lane >= 1 ? x * x : 0.0);
+        double const alpha = __shfl(x, 0);
+        double t = 0.0, beta = alpha, scale = 0.0;
+        if (ss != 0.0) { beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
+        double const v = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
+        HV[k * R2 + lane] = v; s_v[lane] = v;
+        if (lane == 0) { HT[k] = t; s_th = t; }
+        if (lane < len) col[lane] = lane == 0 ? beta : 0.0;
+    } else {
+        for (int idx = tid - 64; idx < len * len; idx += QT - 64) {
+            int const i = idx % len, j = idx / len;
+            Bs[j * LQ + i] = B[(size_t)(p + j) * ldb + p + i];
+        }
+    }
+    __syncthreads();
+    if (tid < len) {                       // u = v^T Bb
+        double u = 0.0;
+        for (int i = 0; i < len; i++) u += s_v[i] * Bs[tid * LQ + i];
+        s_u[tid] = u * s_th;
+    }
+    __syncthreads();
+    // P(a, b) = M(b + 1, a) = Bb(b + 1, a) - th v(b + 1) u(a): len rows, len - 1 columns
     for (int idx = tid; idx < len * kq; idx += QT) {
         int const a = idx % len, b = idx / len;
-        P[b * LQ + a] = B[(size_t)(p + a) * ldb + p + b + 1];
+        P[b * LQ + a] = Bs[a * LQ + b + 1] - s_v[b + 1] * s_u[a];
     }
     __syncthreads();
     group_qr<R2 / 16>(P, LQ, len, kq, tau, scl);
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(QT) void ht2_geng_kernel(Wave2 w, double const *__r
         if (l == 0) GT[k] = t;
     }
 }
-constexpr int GENG_LDS_BYTES = (R2 * (R2 + 1) + 3 * R2 + 16) * 8;
+constexpr int GEN_LDS_BYTES = (2 * R2 * (R2 + 1) + 4 * R2 + 16) * 8;
 
 constexpr int RING = 8;             // factor slots in flight between the critical stream and the stream of Q and Z
 struct Ht2Workspace {
@@ -374,7 +407,7 @@ struct Ht2Workspace {
         if (!attr) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_geng_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GENG_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             for (int k = 0; k < RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready2[k], hipEventDisableTiming));
@@ -499,18 +532,16 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         int const sl = slot_begin();
         double *HV = ws.HV + (size_t)sl * ws.maxk * R2, *HT = ws.HT + (size_t)sl * ws.maxk;
         double *GV = ws.GV + (size_t)sl * ws.maxk * R2, *GT = ws.GT + (size_t)sl * ws.maxk;
-        hipLaunchKernelGGL(ht2_genh_kernel, dim3(count), dim3(64), 0, s, w, A, lda, HV, HT);
+        hipLaunchKernelGGL(ht2_gen_kernel, dim3(count), dim3(QT), GEN_LDS_BYTES, s, w, A, lda, B, ldb, HV, HT, GV, GT);
         slot_ready(sl, ws.ready);
-        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, 256), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, HV, HT);
-        if (Q)
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 1), dim3(256), 0, sq, w,
-                RightTargets{{Q, nullptr, nullptr}, {ldq, 0, 0}, {0, 0, 0}}, n, HV, HT);
-        hipLaunchKernelGGL(ht2_geng_kernel, dim3(count), dim3(QT), GENG_LDS_BYTES, s, w, B, ldb, GV, GT);
-        slot_ready(sl, ws.ready2);
-        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 2), dim3(256), 0, s, w,
+        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, HV, HT);
+        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 2), dim3(256), 0, s, w,
             RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, GV, GT);
+        if (Q)
+            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 1), dim3(256), 0, sq, w,
+                RightTargets{{Q, nullptr, nullptr}, {ldq, 0, 0}, {0, 0, 0}}, n, HV, HT);
         if (Z)
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 256), count, 1), dim3(256), 0, sq, w,
+            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 1), dim3(256), 0, sq, w,
                 RightTargets{{Z, nullptr, nullptr}, {ldz, 0, 0}, {0, 0, 0}}, n, GV, GT);
         slot_end(sl);
     }
