@@ -202,9 +202,13 @@ __global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int
 constexpr int PANEL_LDS_BYTES = (R2 * LDP + 2 * R2 * R2 + 2 * R2 + 16) * 8;
 
 // ---- stage 2 --------------------------------------------------------------------------------------------------
-struct Wave2 { int n, tau_idx, jlo, count; };      // wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - 3 j
+// wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - 3 j.  The reflectors of a step are kept
+// until the GROUP of its sweep (GS consecutive sweeps) has gone through: slot (j / GS) mod nslot of the store,
+// entry (j mod GS) * tstride + t there.
+constexpr int GS = 64;
+struct Wave2 { int n, tau_idx, jlo, count, tstride, nslot; };
 
-__device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, int &c0)
+__device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, int &c0, int &ridx)
 {
     int const j = w.jlo + k, t = w.tau_idx - 3 * j;
     if (k >= w.count || t < 0 || j > w.n - 3) return false;
@@ -212,6 +216,7 @@ __device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, 
     if (p > w.n - 2) return false;
     p1 = min(p + R2, w.n);
     c0 = (t == 0) ? j : p - R2;
+    ridx = (((j / GS) % w.nslot) * GS + j % GS) * w.tstride + t;
     return true;
 }
 
@@ -223,9 +228,9 @@ __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__
     double *__restrict__ B, int ldb, double const *__restrict__ HV, double const *__restrict__ HT)
 {
     int const k = blockIdx.y;
-    int p, p1, c0;
-    if (!step_of(w, k, p, p1, c0)) return;
-    double const tau = HT[k];
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    double const tau = HT[ridx];
     if (tau == 0.0) return;
     bool const isB = blockIdx.z == 1;
     double *X = isB ? B : A;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__
     int const r0 = 4 * l16;
     double v[4];
     #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = (r0 + q < len) ? HV[k * R2 + r0 + q] : 0.0;
+    for (int q = 0; q < 4; q++) v[q] = (r0 + q < len) ? HV[(size_t)ridx * R2 + r0 + q] : 0.0;
     constexpr int NC = LEFT_CHUNK / 16;
     double y[NC][4], d[NC];
     #pragma unroll
@@ -268,9 +273,9 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
 {
     __shared__ double s_d[4][64];
     int const k = blockIdx.y;
-    int p, p1, c0;
-    if (!step_of(w, k, p, p1, c0)) return;
-    double const tau = RT[k];
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    double const tau = RT[ridx];
     int const len = p1 - p, z = blockIdx.z;
     double *X = tg.X[z];
     int const ld = tg.ld[z], kind = tg.kind[z];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
         double y[16], v[16], d = 0.0;
         #pragma unroll
         for (int q = 0; q < 16; q++) {
-            v[q] = q0 + q < len ? RV[k * R2 + q0 + q] : 0.0;
+            v[q] = q0 + q < len ? RV[(size_t)ridx * R2 + q0 + q] : 0.0;
             y[q] = (live && q0 + q < len) ? x[(size_t)q * ld] : 0.0;
             d += y[q] * v[q];
         }
@@ -298,11 +303,11 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
 }
 
 // Both reflectors of every step of the wavefront, one workgroup per step.  Wave 0: the left reflector H = I - th v
-// v^T from A's overhanging column (v -> HV[k], th -> HT[k]; the column is reduced in place).  All: the block
+// v^T from A's overhanging column (v, th -> the step's entry of HV, HT; the column is reduced in place).  All: the block
 // Bb = B(p:p1, p:p1) as it stands BEFORE H (the wide left application of this wavefront follows this kernel and
 // does not have to precede it), M = H Bb formed in LDS, then the opposite reflector: x orthogonal to rows 1 ..
 // len-1 of M (QR of those rows, transposed; x = the last column of the full Q) and G = I - tz w w^T with
-// G e_1 = +-x (w -> GV[k], tz -> GT[k]).  Bb is a full block (the bulge of B travels with the sweep; a step
+// G e_1 = +-x (w, tz -> GV, GT).  Bb is a full block (the bulge of B travels with the sweep; a step
 // restores its first column only), so there is no triangular short cut to x.
 __global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
     double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT)
@@ -312,12 +317,9 @@ __global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict
     double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
     __shared__ double s_th;
     int const k = blockIdx.x, tid = threadIdx.x;
-    int p, p1, c0;
-    if (!step_of(w, k, p, p1, c0)) {
-        if (tid == 0) { GT[k] = 0.0; HT[k] = 0.0; }
-        if (tid < R2) { GV[k * R2 + tid] = 0.0; HV[k * R2 + tid] = 0.0; }
-        return;
-    }
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    HV += (size_t)ridx * R2; GV += (size_t)ridx * R2; HT += ridx; GT += ridx;
     int const len = p1 - p, kq = len - 1;
     if (tid < 64) {
         int const lane = tid;
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict
         double t = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) { beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
         double const v = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
-        HV[k * R2 + lane] = v; s_v[lane] = v;
-        if (lane == 0) { HT[k] = t; s_th = t; }
+        HV[lane] = v; s_v[lane] = v;
+        if (lane == 0) { HT[0] = t; s_th = t; }
         if (lane < len) col[lane] = lane == 0 ? beta : 0.0;
     } else {
         for (int idx = tid - 64; idx < len * len; idx += QT - 64) {
@@ -386,32 +388,98 @@ __global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict
         #pragma unroll
         for (int r = 0; r < 4; r++) {
             int const i = l + 16 * r;
-            GV[k * R2 + i] = i == 0 ? 1.0 : (i < len ? ev[r] * scale : 0.0);
+            GV[i] = i == 0 ? 1.0 : (i < len ? ev[r] * scale : 0.0);
         }
-        if (l == 0) GT[k] = t;
+        if (l == 0) GT[0] = t;
     }
 }
 constexpr int GEN_LDS_BYTES = (2 * R2 * (R2 + 1) + 4 * R2 + 16) * 8;
 
-constexpr int RING = 8;             // factor slots in flight between the critical stream and the stream of Q and Z
+// Q and Z do not take part in the chase: the reflectors of a group of GS sweeps are applied to them once the group
+// is through, position by position as compact-WY blocks.  The reflectors (j0 + jj, t), jj = 0 .. k-1, of position t
+// act on the columns col0 + jj .. col0 + jj + len - 1 (col0 = j0 + 1 + 64 t): V is a (k - 1 + 64) x k parallelogram.
+// Blocks of one group go in DEcreasing t: reflector (j, t + 1) overlaps (j', t) in one column exactly when j' > j,
+// and the chase applies it first; all other pairs of different positions are disjoint.  This kernel: V (leading
+// dimension 2 r, zero filled) and T (leading dimension k) of every position of the group, for the left reflectors
+// (blockIdx.y = 0, for Q) and the opposite ones (1, for Z).  T as in lds_tfactor.
+constexpr int LDVS = 2 * R2 + 1;
+__global__ __launch_bounds__(QT) void ht2_group_wy_kernel(int n, int j0, int gsize, int tstride, int slot,
+    double const *__restrict__ HV, double const *__restrict__ HT, double const *__restrict__ GV, double const *__restrict__ GT,
+    double *__restrict__ Vb, double *__restrict__ Tb)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *V = lds, *G = V + R2 * LDVS, *T = G + R2 * R2, *tau = T + R2 * R2;
+    int const t = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+    int const col0 = j0 + 1 + R2 * t;
+    int const k = min(gsize, n - 1 - col0);                 // sweeps with p = col0 + jj <= n - 2
+    if (k <= 0) return;
+    int const m = min(k - 1 + R2, n - col0);
+    double const *RV = which ? GV : HV, *RT = which ? GT : HT;
+    for (int e = tid; e < R2 * LDVS; e += QT) V[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < k * R2; e += QT) {
+        int const jj = e / R2, i = e % R2;
+        size_t const ridx = (size_t)(slot * GS + jj) * tstride + t;
+        int const len = min(R2, n - (col0 + jj));
+        if (i < len) V[jj * LDVS + jj + i] = RV[ridx * R2 + i];
+        if (i == 0) tau[jj] = RT[ridx];
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += QT) {
+        int const i = e % k, j = e / k;
+        T[j * R2 + i] = 0.0;
+        if (i >= j) continue;
+        double g = 0.0;
+        for (int r = j; r < min(i + R2, m); r++) g += V[i * LDVS + r] * V[j * LDVS + r];
+        G[j * k + i] = g;
+    }
+    __syncthreads();
+    if (tid < k) {
+        int const i = tid;
+        T[i * R2 + i] = tau[i];
+        for (int j = i + 1; j < k; j++) {
+            double g = 0.0;
+            for (int l = i; l < j; l++) g += T[l * R2 + i] * G[j * k + l];
+            T[j * R2 + i] = -tau[j] * g;
+        }
+    }
+    __syncthreads();
+    double *Vo = Vb + ((size_t)which * tstride + t) * (2 * R2 * R2), *To = Tb + ((size_t)which * tstride + t) * (R2 * R2);
+    for (int e = tid; e < k * 2 * R2; e += QT) { int const r = e % (2 * R2), jj = e / (2 * R2); Vo[(size_t)jj * 2 * R2 + r] = V[jj * LDVS + r]; }
+    for (int e = tid; e < k * k; e += QT) To[e] = T[(e / k) * R2 + e % k];
+}
+constexpr int GROUP_LDS_BYTES = (R2 * LDVS + 2 * R2 * R2 + R2 + 16) * 8;
+
+constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
+constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
+inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
+// a group is in the chase for 3 (GS - 1) + tstride wavefronts, the next one starts 3 GS wavefronts after it; one
+// more slot for the group whose blocks the second stream is still applying
+inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + 3 * GS - 3) / (3 * GS) + 2); }
 struct Ht2Workspace {
     int n = 0;
     double *V = nullptr, *T = nullptr;              // stage 1: RING slots of (2r x r) and (r x r)
     double *W1 = nullptr, *W2 = nullptr, *W1q = nullptr, *W2q = nullptr;   // GEMM scratch of the two streams
-    double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: RING slots of maxk reflectors
+    double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
+    double *Vb = nullptr, *Tb = nullptr;            // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
     int maxk = 0;
     bool attr = false;
-    hipEvent_t ready[RING] = {}, ready2[RING] = {}, used[RING] = {}, tail = nullptr;
+    hipEvent_t ready[RING] = {}, used[RING] = {}, tail = nullptr;
+    hipEvent_t through[MAXSLOT] = {}, applied[MAXSLOT] = {};
     void ensure(int n_)
     {
         if (!attr) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
             for (int k = 0; k < RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
-                SN_HIP_CHECK(hipEventCreateWithFlags(&ready2[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&used[k], hipEventDisableTiming));
+            }
+            for (int k = 0; k < MAXSLOT; k++) {
+                SN_HIP_CHECK(hipEventCreateWithFlags(&through[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&applied[k], hipEventDisableTiming));
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&tail, hipEventDisableTiming));
             attr = true;
@@ -423,11 +491,13 @@ struct Ht2Workspace {
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
         alloc(V, (size_t)RING * 2 * R2 * R2); alloc(T, (size_t)RING * R2 * R2);
         alloc(W1, (size_t)R2 * n); alloc(W2, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n); alloc(W2q, (size_t)R2 * n);
-        alloc(HV, (size_t)RING * maxk * R2); alloc(HT, (size_t)RING * maxk); alloc(GV, (size_t)RING * maxk * R2); alloc(GT, (size_t)RING * maxk);
+        size_t const refl = (size_t)ht2_nslot(n) * GS * ht2_tstride(n);
+        alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
+        alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(Tb, (size_t)2 * ht2_tstride(n) * R2 * R2);
     }
     void release()
     {
-        double **all[] = {&V, &T, &W1, &W2, &W1q, &W2q, &HV, &HT, &GV, &GT};
+        double **all[] = {&V, &T, &W1, &W2, &W1q, &W2q, &HV, &HT, &GV, &GT, &Vb, &Tb};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
@@ -472,10 +542,10 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         if (slot_count >= RING && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.used[k], 0));
         return k;
     };
-    auto slot_ready = [&](int k, hipEvent_t *ev) {
+    auto slot_ready = [&](int k) {
         if (sq == s) return;
-        SN_HIP_CHECK(hipEventRecord(ev[k], s));
-        SN_HIP_CHECK(hipStreamWaitEvent(sq, ev[k], 0));
+        SN_HIP_CHECK(hipEventRecord(ws.ready[k], s));
+        SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[k], 0));
     };
     auto slot_end = [&](int k) {
         if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.used[k], sq));
@@ -490,7 +560,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             int const m = i1 - i0, k = nb, sl = slot_begin();
             double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
             hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, V, 2 * r, T);
-            slot_ready(sl, ws.ready);
+            slot_ready(sl);
             wy_left(s, V, T, ws.W1, ws.W2, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
             wy_left(s, V, T, ws.W1, ws.W2, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
             if (Q) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, k, Q + (size_t)i0 * ldq, ldq);
@@ -501,7 +571,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             int const m = i1 - i0, sl = slot_begin();
             double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
             hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, 2 * r, T);
-            slot_ready(sl, ws.ready);
+            slot_ready(sl);
             wy_right(s, V, T, ws.W1, ws.W2, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
             wy_right(s, V, T, ws.W1, ws.W2, n, m, mb, A + (size_t)i0 * lda, lda);
             if (Z) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
@@ -520,6 +590,29 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     }
     if (between) SN_HIP_CHECK(hipEventRecord(between, s));
     // ---- stage 2 -----------------------------------------------------------------------------------------------
+    int const tstride = ht2_tstride(n), nslot = ht2_nslot(n), ngroups = (n - 2 + GS - 1) / GS;
+    int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q and Z
+    // the last wavefront with a step of group g: its last sweep jl at its last position
+    auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return 3 * jl + (n - 3 - jl) / R2; };
+    auto close_group = [&](int g) {
+        int const j0 = g * GS, gsize = std::min(GS, n - 2 - j0), slot = g % nslot;
+        int const tcount = (n - 3 - j0) / R2 + 1;
+        if (Q || Z) {
+            if (sq != s) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
+            hipLaunchKernelGGL(ht2_group_wy_kernel, dim3(tcount, 2), dim3(QT), GROUP_LDS_BYTES, sq, n, j0, gsize, tstride, slot,
+                ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.Tb);
+            for (int t = tcount - 1; t >= 0; t--) {
+                int const col0 = j0 + 1 + R2 * t, k = std::min(gsize, n - 1 - col0);
+                if (k <= 0) continue;
+                int const m = std::min(k - 1 + R2, n - col0);
+                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.Tb + (size_t)t * R2 * R2, ws.W1q, ws.W2q, n, m, k,
+                    Q + (size_t)col0 * ldq, ldq);
+                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.Tb + (size_t)(tstride + t) * R2 * R2, ws.W1q, ws.W2q,
+                    n, m, k, Z + (size_t)col0 * ldz, ldz);
+            }
+            if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
+        }
+    };
     for (int tau_idx = 0;; tau_idx++) {
         int const jhi = std::min(tau_idx / 3, n - 3);
         // position t = tau_idx - 3 j must satisfy j + 1 + t r <= n - 2
@@ -528,23 +621,17 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         if (jlo > jhi) { if (tau_idx / 3 >= n - 3) break; else continue; }
         int const count = jhi - jlo + 1;
         if (count > ws.maxk) return -1;
-        Wave2 const w{n, tau_idx, jlo, count};
-        int const sl = slot_begin();
-        double *HV = ws.HV + (size_t)sl * ws.maxk * R2, *HT = ws.HT + (size_t)sl * ws.maxk;
-        double *GV = ws.GV + (size_t)sl * ws.maxk * R2, *GT = ws.GT + (size_t)sl * ws.maxk;
-        hipLaunchKernelGGL(ht2_gen_kernel, dim3(count), dim3(QT), GEN_LDS_BYTES, s, w, A, lda, B, ldb, HV, HT, GV, GT);
-        slot_ready(sl, ws.ready);
-        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, HV, HT);
+        for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
+            if (opened >= nslot && sq != s && (Q || Z)) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.applied[opened % nslot], 0));
+        if (opened - closed > nslot) return -2;
+        Wave2 const w{n, tau_idx, jlo, count, tstride, nslot};
+        hipLaunchKernelGGL(ht2_gen_kernel, dim3(count), dim3(QT), GEN_LDS_BYTES, s, w, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT);
+        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT);
         hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 2), dim3(256), 0, s, w,
-            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, GV, GT);
-        if (Q)
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 1), dim3(256), 0, sq, w,
-                RightTargets{{Q, nullptr, nullptr}, {ldq, 0, 0}, {0, 0, 0}}, n, HV, HT);
-        if (Z)
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 1), dim3(256), 0, sq, w,
-                RightTargets{{Z, nullptr, nullptr}, {ldz, 0, 0}, {0, 0, 0}}, n, GV, GT);
-        slot_end(sl);
+            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
+        for (; closed < ngroups && last_wave(closed) <= tau_idx; closed++) close_group(closed);
     }
+    for (; closed < ngroups; closed++) close_group(closed);
     if (sq != s) {
         SN_HIP_CHECK(hipEventRecord(ws.tail, sq));
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.tail, 0));
