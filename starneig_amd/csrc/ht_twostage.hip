@@ -83,7 +83,25 @@ __device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *
         for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i > c) s += x[r] * x[r]; if (i == c) alpha = x[r]; }
         s = row16_sum(s); alpha = row16_sum(alpha);
         double t = 0.0, beta = alpha, scale = 0.0;
-        if (s != 0.0) { beta = -copysign(sqrt(alpha * alpha + s), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
+        if (s != 0.0) {
+            double const nn = alpha * alpha + s;
+            if (nn > 1e-280 && nn < 1e280) {
+                // the chain of a column ends in these scalars: hardware reciprocal square root and reciprocal with
+                // two Newton steps each (a few ulp) instead of the correctly rounded sqrt and two divisions --
+                // 120 of the 2100 cycles of a column (scratch/micro/qr_phases.hip)
+                double rs = __builtin_amdgcn_rsq(nn);
+                rs = rs * (1.5 - 0.5 * nn * rs * rs);
+                rs = rs * (1.5 - 0.5 * nn * rs * rs);
+                beta = -copysign(nn * rs, alpha);
+                t = (beta - alpha) * -copysign(rs, alpha);
+                double const dd = alpha - beta;
+                double rc = __builtin_amdgcn_rcp(dd);
+                rc = rc * (2.0 - dd * rc);
+                scale = rc * (2.0 - dd * rc);
+            } else {
+                beta = -copysign(sqrt(nn), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta);
+            }
+        }
         #pragma unroll
         for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i < m) P[c * ldp + i] = (i == c) ? beta : x[r]; }
         if (l == 0) { tau[c] = t; scl[c] = scale; piv[c & 1][0] = t; piv[c & 1][1] = scale; }
@@ -121,85 +139,149 @@ __device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *
     __syncthreads();
 }
 
-// T (k x k, upper triangular, leading dimension ldt, in LDS) of the compact-WY form H_0 H_1 ... H_{k-1} =
-// I - V T V^T from the panel group_qr left (v_c = [0 .. 0, 1, scl[c] P(c+1:m, c)]; LAPACK dlarft, forward /
-// columnwise).  All threads of the workgroup: the Gram matrix entry by entry, then every row of T by its own
-// thread (row i of T depends on row i alone).  G: k x k scratch in LDS.
-__device__ void lds_tfactor(double const *P, int ldp, int m, int k, double const *tau, double const *scl,
-    double *T, int ldt, double *G)
+typedef double d4v __attribute__((ext_vector_type(4)));
+// One 16 x 16 tile D(i, j) = sum_{k < K} a(i, k) b(k, j) on the matrix core (v_mfma_f64_16x16x4_f64), K a multiple of
+// 4, operands through accessors (LDS): lane l ends with D(i = (l >> 4) + 4 reg, j = l & 15) in component reg.
+template <class FA, class FB>
+__device__ __forceinline__ d4v wave_tile(int K, FA a, FB b)
 {
-    int const tid = threadIdx.x, nt = blockDim.x;
-    for (int e = tid; e < k * k; e += nt) {
-        int const i = e % k, j = e / k;
-        T[j * ldt + i] = 0.0;
-        if (i >= j) continue;
-        double s = 0.0;
-        for (int r = j + 1; r < m; r++) s += P[i * ldp + r] * P[j * ldp + r];
-        // v_i^T v_j = v_i(j) * 1 + sum_{r > j} v_i(r) v_j(r)
-        G[j * k + i] = scl[i] * ((j < m ? P[i * ldp + j] : 0.0) + scl[j] * s);
-    }
-    __syncthreads();
-    if (tid < k) {
-        int const i = tid;
-        T[i * ldt + i] = tau[i];
-        for (int j = i + 1; j < k; j++) {
-            double s = 0.0;
-            for (int l = i; l < j; l++) s += T[l * ldt + i] * G[j * k + l];
-            T[j * ldt + i] = -tau[j] * s;
-        }
+    int const l = threadIdx.x & 63, q = l & 15, kk = l >> 4;
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(q, k0 + kk), b(k0 + kk, q), acc, 0, 0, 0);
+    return acc;
+}
+
+// The panel group_qr left (R and the unscaled tails) becomes the explicit V in place: 2 r rows x r columns, unit
+// lower trapezoidal, zero beyond m rows and k columns.
+__device__ void lds_explicit_v(double *P, int ldp, int m, int k, double const *scl)
+{
+    for (int e = threadIdx.x; e < 2 * R2 * R2; e += blockDim.x) {
+        int const r = e % (2 * R2), c = e / (2 * R2);
+        double v = 0.0;
+        if (c < k && r < m) v = r > c ? P[c * ldp + r] * scl[c] : (r == c ? 1.0 : 0.0);
+        P[c * ldp + r] = v;
     }
     __syncthreads();
 }
 
+// T (r x r, upper triangular, leading dimension R2, in LDS) of the compact-WY form H_0 H_1 ... H_{k-1} = I - V T V^T
+// (LAPACK dlarft, forward / columnwise) from the explicit V (2 r x r, zero padded; tau[c] = 0 for c >= k).
+// G = V^T V on the matrix core; the two 32 x 32 diagonal blocks of T row by row (row i of T depends on row i
+// alone: T(i, j) = -tau_j sum_{i <= l < j} T(i, l) G(l, j)), two half waves side by side; the block above the
+// diagonal T12 = -T11 (G12 T22) on the matrix core again.  G: r x r scratch, W: 32 x 32 scratch, both in LDS.
+// (The first version summed the Gram matrix entry by entry from LDS -- a million reads, 23 us of a 120 us panel --
+// and ran all 64 rows of the recurrence through one wave, 9 us.)
+__device__ void lds_tfactor(double const *V, int ldv, double const *tau, double *T, double *G, double *W)
+{
+    int const tid = threadIdx.x, wave = tid >> 6, l = tid & 63, q = l & 15, kk = l >> 4;
+    constexpr int H = R2 / 2;
+    for (int e = tid; e < R2 * R2; e += blockDim.x) T[e] = 0.0;
+    {   // the ten upper 16 x 16 tiles of G, one per wave
+        int ti = 0, tj = 0, idx = wave;
+        bool mine = false;
+        for (int a = 0; a < 4 && !mine; a++) for (int b = a; b < 4; b++) { if (idx == 0) { ti = a; tj = b; mine = true; break; } idx--; }
+        if (mine) {
+            d4v const d = wave_tile(2 * R2, [&](int i, int k) { return V[(16 * ti + i) * ldv + k]; },
+                                            [&](int k, int j) { return V[(16 * tj + j) * ldv + k]; });
+            #pragma unroll
+            for (int reg = 0; reg < 4; reg++) G[(16 * tj + q) * R2 + 16 * ti + kk + 4 * reg] = d[reg];
+        }
+    }
+    __syncthreads();
+    if (tid < R2) {
+        int const i = tid, hi = (i / H + 1) * H;           // rows 0 .. 31: columns < 32, rows 32 .. 63: columns < 64
+        T[i * R2 + i] = tau[i];
+        for (int j = i + 1; j < hi; j++) {
+            double g = 0.0;
+            for (int c = i; c < j; c++) g += T[c * R2 + i] * G[j * R2 + c];
+            T[j * R2 + i] = -tau[j] * g;
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {                                          // W = G12 T22
+        int const ti = wave & 1, tj = wave >> 1;
+        d4v const d = wave_tile(H, [&](int i, int k) { return G[(H + k) * R2 + 16 * ti + i]; },
+                                   [&](int k, int j) { return T[(H + 16 * tj + j) * R2 + H + k]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) W[(16 * tj + q) * H + 16 * ti + kk + 4 * reg] = d[reg];
+    }
+    __syncthreads();
+    if (wave < 4) {                                          // T12 = -T11 W
+        int const ti = wave & 1, tj = wave >> 1;
+        d4v const d = wave_tile(H, [&](int i, int k) { return T[k * R2 + 16 * ti + i]; },
+                                   [&](int k, int j) { return W[(16 * tj + j) * H + k]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) T[(H + 16 * tj + q) * R2 + 16 * ti + kk + 4 * reg] = -d[reg];
+    }
+    __syncthreads();
+}
+
+// (V T^T)(row, c) for the 16 x 16 tiles of the 2 r x r product, two per wave of a 1024-thread workgroup, handed to
+// `out(row, c, value)`: with it a compact-WY block costs two GEMMs instead of three (X -= (V T^T) (V^T X),
+// X -= (X V) (V T^T)^T)
+template <class OUT>
+__device__ void lds_vtt(double const *V, int ldv, double const *T, OUT out)
+{
+    int const wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & 15, kk = l >> 4;
+    for (int tile = wave; tile < (2 * R2 / 16) * (R2 / 16); tile += blockDim.x / 64) {
+        int const tr = tile % (2 * R2 / 16), tc = tile / (2 * R2 / 16);
+        d4v const d = wave_tile(R2, [&](int i, int k) { return V[k * ldv + 16 * tr + i]; },
+                                    [&](int k, int j) { return T[k * R2 + 16 * tc + j]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) out(16 * tr + kk + 4 * reg, 16 * tc + q, d[reg]);
+    }
+}
+
 // Stage 1, left: QR of the m x nb block X = A(i0:i0+m, jc:jc+nb) (m <= 2 r, nb <= r); R back in place with
-// exact zeros below it, V (m x nb, unit lower trapezoidal, leading dimension ldv) and T (nb x nb, ld R2) out.
+// exact zeros below it, V (m x nb, unit lower trapezoidal) and V T^T (m x nb) out, leading dimension ldv both.
 __global__ __launch_bounds__(QT) void ht2_panel_qr_kernel(double *__restrict__ X, int ldx, int m, int nb,
-    double *__restrict__ V, int ldv, double *__restrict__ T)
+    double *__restrict__ V, double *__restrict__ VT, int ldv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *P = lds, *Tl = P + R2 * LDP, *G = Tl + R2 * R2, *tau = G + R2 * R2, *scl = tau + R2;
+    double *P = lds, *Tl = P + R2 * LDP, *G = Tl + R2 * R2, *W = G + R2 * R2, *tau = W + R2 * R2 / 4, *scl = tau + R2;
     int const tid = threadIdx.x;
     for (int e = tid; e < m * nb; e += QT) { int const i = e % m, j = e / m; P[j * LDP + i] = X[(size_t)j * ldx + i]; }
+    if (tid >= nb && tid < R2) tau[tid] = 0.0;
     __syncthreads();
     group_qr<2 * R2 / 16>(P, LDP, m, nb, tau, scl);
-    lds_tfactor(P, LDP, m, nb, tau, scl, Tl, R2, G);
-    for (int e = tid; e < m * nb; e += QT) {
-        int const i = e % m, j = e / m;
-        double const x = P[j * LDP + i];
-        X[(size_t)j * ldx + i] = (i <= j) ? x : 0.0;
-        V[(size_t)j * ldv + i] = (i > j) ? x * scl[j] : (i == j ? 1.0 : 0.0);
-    }
-    for (int e = tid; e < nb * nb; e += QT) T[e] = Tl[(e / nb) * R2 + e % nb] * ((e % nb) <= (e / nb) ? 1.0 : 0.0);
+    for (int e = tid; e < m * nb; e += QT) { int const i = e % m, j = e / m; X[(size_t)j * ldx + i] = (i <= j) ? P[j * LDP + i] : 0.0; }
+    __syncthreads();
+    lds_explicit_v(P, LDP, m, nb, scl);
+    lds_tfactor(P, LDP, tau, Tl, G, W);
+    for (int e = tid; e < m * nb; e += QT) { int const i = e % m, j = e / m; V[(size_t)j * ldv + i] = P[j * LDP + i]; }
+    lds_vtt(P, LDP, Tl, [&](int row, int c, double x) { if (row < m && c < nb) VT[(size_t)c * ldv + row] = x; });
 }
 
 // Stage 1, right: the mb x m block Mb = B(i1-mb:i1, i0:i1) (mb <= r, m <= 2 r) becomes [0 R] (R mb x mb upper
 // triangular) under G = I - V T V^T from the right: QR of the flipped transpose, flip(Mb^T) = Qr R, G = flip Qr flip.
-// V: m x mb (rows = columns of the block), T: mb x mb.
+// V, V T^T: m x mb (rows = columns of the block).
 __global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int ldb, int mb, int m,
-    double *__restrict__ V, int ldv, double *__restrict__ T)
+    double *__restrict__ V, double *__restrict__ VT, int ldv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *P = lds, *Tl = P + R2 * LDP, *G = Tl + R2 * R2, *tau = G + R2 * R2, *scl = tau + R2;
+    double *P = lds, *Tl = P + R2 * LDP, *G = Tl + R2 * R2, *W = G + R2 * R2, *tau = W + R2 * R2 / 4, *scl = tau + R2;
     int const tid = threadIdx.x;
     // P(a, b) = Mb(mb-1-b, m-1-a): m rows, mb columns
     for (int e = tid; e < m * mb; e += QT) {
-        int const a = e % m, b = e / m;
+        int const b = e % mb, a = e / mb;
         P[b * LDP + a] = Mb[(size_t)(m - 1 - a) * ldb + (mb - 1 - b)];
     }
+    if (tid >= mb && tid < R2) tau[tid] = 0.0;
     __syncthreads();
     group_qr<2 * R2 / 16>(P, LDP, m, mb, tau, scl);
-    lds_tfactor(P, LDP, m, mb, tau, scl, Tl, R2, G);
+    // Mb_new(q, c) = R(m-1-c, mb-1-q)
     for (int e = tid; e < m * mb; e += QT) {
-        int const a = e % m, b = e / m;
-        double const x = P[b * LDP + a];
-        // Mb_new(q, c) = R(m-1-c, mb-1-q)
-        Mb[(size_t)(m - 1 - a) * ldb + (mb - 1 - b)] = (a <= b) ? x : 0.0;
-        // V(row = column index of the block) = flipped rows of Vr
-        V[(size_t)b * ldv + (m - 1 - a)] = (a > b) ? x * scl[b] : (a == b ? 1.0 : 0.0);
+        int const b = e % mb, a = e / mb;
+        Mb[(size_t)(m - 1 - a) * ldb + (mb - 1 - b)] = (a <= b) ? P[b * LDP + a] : 0.0;
     }
-    for (int e = tid; e < mb * mb; e += QT) T[e] = Tl[(e / mb) * R2 + e % mb] * ((e % mb) <= (e / mb) ? 1.0 : 0.0);
+    __syncthreads();
+    lds_explicit_v(P, LDP, m, mb, scl);
+    lds_tfactor(P, LDP, tau, Tl, G, W);
+    // V(row = column index of the block) = flipped rows of Vr
+    for (int e = tid; e < m * mb; e += QT) { int const a = e % m, b = e / m; V[(size_t)b * ldv + (m - 1 - a)] = P[b * LDP + a]; }
+    lds_vtt(P, LDP, Tl, [&](int row, int c, double x) { if (row < m && c < mb) VT[(size_t)c * ldv + (m - 1 - row)] = x; });
 }
-constexpr int PANEL_LDS_BYTES = (R2 * LDP + 2 * R2 * R2 + 2 * R2 + 16) * 8;
+constexpr int PANEL_LDS_BYTES = (R2 * LDP + 2 * R2 * R2 + R2 * R2 / 4 + 2 * R2 + 16) * 8;
 
 // ---- stage 2 --------------------------------------------------------------------------------------------------
 // wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - 3 j.  The reflectors of a step are kept
@@ -399,23 +481,23 @@ constexpr int GEN_LDS_BYTES = (2 * R2 * (R2 + 1) + 4 * R2 + 16) * 8;
 // is through, position by position as compact-WY blocks.  The reflectors (j0 + jj, t), jj = 0 .. k-1, of position t
 // act on the columns col0 + jj .. col0 + jj + len - 1 (col0 = j0 + 1 + 64 t): V is a (k - 1 + 64) x k parallelogram.
 // Blocks of one group go in DEcreasing t: reflector (j, t + 1) overlaps (j', t) in one column exactly when j' > j,
-// and the chase applies it first; all other pairs of different positions are disjoint.  This kernel: V (leading
-// dimension 2 r, zero filled) and T (leading dimension k) of every position of the group, for the left reflectors
-// (blockIdx.y = 0, for Q) and the opposite ones (1, for Z).  T as in lds_tfactor.
+// and the chase applies it first; all other pairs of different positions are disjoint.  This kernel: V and V T^T
+// (leading dimension 2 r, zero filled) of every position of the group, for the left reflectors
+// (blockIdx.y = 0, for Q) and the opposite ones (1, for Z).
 constexpr int LDVS = 2 * R2 + 1;
 __global__ __launch_bounds__(QT) void ht2_group_wy_kernel(int n, int j0, int gsize, int tstride, int slot,
     double const *__restrict__ HV, double const *__restrict__ HT, double const *__restrict__ GV, double const *__restrict__ GT,
-    double *__restrict__ Vb, double *__restrict__ Tb)
+    double *__restrict__ Vb, double *__restrict__ VTb)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *V = lds, *G = V + R2 * LDVS, *T = G + R2 * R2, *tau = T + R2 * R2;
+    double *V = lds, *G = V + R2 * LDVS, *T = G + R2 * R2, *W = T + R2 * R2, *tau = W + R2 * R2 / 4;
     int const t = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
     int const col0 = j0 + 1 + R2 * t;
     int const k = min(gsize, n - 1 - col0);                 // sweeps with p = col0 + jj <= n - 2
     if (k <= 0) return;
-    int const m = min(k - 1 + R2, n - col0);
     double const *RV = which ? GV : HV, *RT = which ? GT : HT;
     for (int e = tid; e < R2 * LDVS; e += QT) V[e] = 0.0;
+    if (tid < R2) tau[tid] = 0.0;
     __syncthreads();
     for (int e = tid; e < k * R2; e += QT) {
         int const jj = e / R2, i = e % R2;
@@ -425,30 +507,12 @@ __global__ __launch_bounds__(QT) void ht2_group_wy_kernel(int n, int j0, int gsi
         if (i == 0) tau[jj] = RT[ridx];
     }
     __syncthreads();
-    for (int e = tid; e < k * k; e += QT) {
-        int const i = e % k, j = e / k;
-        T[j * R2 + i] = 0.0;
-        if (i >= j) continue;
-        double g = 0.0;
-        for (int r = j; r < min(i + R2, m); r++) g += V[i * LDVS + r] * V[j * LDVS + r];
-        G[j * k + i] = g;
-    }
-    __syncthreads();
-    if (tid < k) {
-        int const i = tid;
-        T[i * R2 + i] = tau[i];
-        for (int j = i + 1; j < k; j++) {
-            double g = 0.0;
-            for (int l = i; l < j; l++) g += T[l * R2 + i] * G[j * k + l];
-            T[j * R2 + i] = -tau[j] * g;
-        }
-    }
-    __syncthreads();
-    double *Vo = Vb + ((size_t)which * tstride + t) * (2 * R2 * R2), *To = Tb + ((size_t)which * tstride + t) * (R2 * R2);
+    lds_tfactor(V, LDVS, tau, T, G, W);
+    double *Vo = Vb + ((size_t)which * tstride + t) * (2 * R2 * R2), *VTo = VTb + ((size_t)which * tstride + t) * (2 * R2 * R2);
     for (int e = tid; e < k * 2 * R2; e += QT) { int const r = e % (2 * R2), jj = e / (2 * R2); Vo[(size_t)jj * 2 * R2 + r] = V[jj * LDVS + r]; }
-    for (int e = tid; e < k * k; e += QT) To[e] = T[(e / k) * R2 + e % k];
+    lds_vtt(V, LDVS, T, [&](int row, int c, double x) { if (c < k) VTo[(size_t)c * 2 * R2 + row] = x; });
 }
-constexpr int GROUP_LDS_BYTES = (R2 * LDVS + 2 * R2 * R2 + R2 + 16) * 8;
+constexpr int GROUP_LDS_BYTES = (R2 * LDVS + 2 * R2 * R2 + R2 * R2 / 4 + R2 + 16) * 8;
 
 constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
 constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
@@ -458,10 +522,10 @@ inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
 inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + 3 * GS - 3) / (3 * GS) + 2); }
 struct Ht2Workspace {
     int n = 0;
-    double *V = nullptr, *T = nullptr;              // stage 1: RING slots of (2r x r) and (r x r)
-    double *W1 = nullptr, *W2 = nullptr, *W1q = nullptr, *W2q = nullptr;   // GEMM scratch of the two streams
+    double *V = nullptr, *VT = nullptr;             // stage 1: RING slots of V and V T^T (2r x r each)
+    double *W1 = nullptr, *W1q = nullptr;           // GEMM scratch of the two streams
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
-    double *Vb = nullptr, *Tb = nullptr;            // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
+    double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
     int maxk = 0;
     bool attr = false;
     hipEvent_t ready[RING] = {}, used[RING] = {}, tail = nullptr;
@@ -489,36 +553,34 @@ struct Ht2Workspace {
         n = n_;
         maxk = n / (3 * R2 - 1) + 4;
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
-        alloc(V, (size_t)RING * 2 * R2 * R2); alloc(T, (size_t)RING * R2 * R2);
-        alloc(W1, (size_t)R2 * n); alloc(W2, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n); alloc(W2q, (size_t)R2 * n);
+        alloc(V, (size_t)RING * 2 * R2 * R2); alloc(VT, (size_t)RING * 2 * R2 * R2);
+        alloc(W1, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n);
         size_t const refl = (size_t)ht2_nslot(n) * GS * ht2_tstride(n);
         alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
-        alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(Tb, (size_t)2 * ht2_tstride(n) * R2 * R2);
+        alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(VTb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2);
     }
     void release()
     {
-        double **all[] = {&V, &T, &W1, &W2, &W1q, &W2q, &HV, &HT, &GV, &GT, &Vb, &Tb};
+        double **all[] = {&V, &VT, &W1, &W1q, &HV, &HT, &GV, &GT, &Vb, &VTb};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
 };
 Ht2Workspace g_ht2;
 
-// X (m x ncols) <- (I - V T V^T)^T X
-void wy_left(hipStream_t s, double const *V, double const *T, double *W1, double *W2, int m, int k, int ncols, double *X, int ldx)
+// X (m x ncols) <- (I - V T V^T)^T X = X - (V T^T) (V^T X)
+void wy_left(hipStream_t s, double const *V, double const *VT, double *W1, int m, int k, int ncols, double *X, int ldx)
 {
     if (ncols <= 0 || k <= 0) return;
     dgemm(s, 'T', 'N', k, ncols, m, 1.0, V, 2 * R2, X, ldx, 0.0, W1, R2);
-    dgemm(s, 'T', 'N', k, ncols, k, 1.0, T, k, W1, R2, 0.0, W2, R2);
-    dgemm(s, 'N', 'N', m, ncols, k, -1.0, V, 2 * R2, W2, R2, 1.0, X, ldx);
+    dgemm(s, 'N', 'N', m, ncols, k, -1.0, VT, 2 * R2, W1, R2, 1.0, X, ldx);
 }
-// X (nrows x m) <- X (I - V T V^T)
-void wy_right(hipStream_t s, double const *V, double const *T, double *W1, double *W2, int nrows, int m, int k, double *X, int ldx)
+// X (nrows x m) <- X (I - V T V^T) = X - (X V) (V T^T)^T
+void wy_right(hipStream_t s, double const *V, double const *VT, double *W1, int nrows, int m, int k, double *X, int ldx)
 {
     if (nrows <= 0 || k <= 0) return;
     dgemm(s, 'N', 'N', nrows, k, m, 1.0, X, ldx, V, 2 * R2, 0.0, W1, nrows);
-    dgemm(s, 'N', 'N', nrows, k, k, 1.0, W1, nrows, T, k, 0.0, W2, nrows);
-    dgemm(s, 'N', 'T', nrows, m, k, -1.0, W2, nrows, V, 2 * R2, 1.0, X, ldx);
+    dgemm(s, 'N', 'T', nrows, m, k, -1.0, W1, nrows, VT, 2 * R2, 1.0, X, ldx);
 }
 
 } // namespace
@@ -558,23 +620,23 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         for (int i = top; i < n; i += r) starts.push_back(i);
         auto left_step = [&](int i0, int i1) {
             int const m = i1 - i0, k = nb, sl = slot_begin();
-            double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
-            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, V, 2 * r, T);
+            double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
+            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, V, VT, 2 * r);
             slot_ready(sl);
-            wy_left(s, V, T, ws.W1, ws.W2, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
-            wy_left(s, V, T, ws.W1, ws.W2, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
-            if (Q) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, k, Q + (size_t)i0 * ldq, ldq);
+            wy_left(s, V, VT, ws.W1, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
+            wy_left(s, V, VT, ws.W1, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
+            if (Q) wy_right(sq, V, VT, ws.W1q, n, m, k, Q + (size_t)i0 * ldq, ldq);
             slot_end(sl);
         };
         auto right_step = [&](int i0, int i1, int mb) {
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
             int const m = i1 - i0, sl = slot_begin();
-            double *V = ws.V + (size_t)sl * 2 * r * r, *T = ws.T + (size_t)sl * r * r;
-            hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, 2 * r, T);
+            double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
+            hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT, 2 * r);
             slot_ready(sl);
-            wy_right(s, V, T, ws.W1, ws.W2, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
-            wy_right(s, V, T, ws.W1, ws.W2, n, m, mb, A + (size_t)i0 * lda, lda);
-            if (Z) wy_right(sq, V, T, ws.W1q, ws.W2q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
+            wy_right(s, V, VT, ws.W1, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
+            wy_right(s, V, VT, ws.W1, n, m, mb, A + (size_t)i0 * lda, lda);
+            if (Z) wy_right(sq, V, VT, ws.W1q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
             slot_end(sl);
         };
         int const K = (int)starts.size();
@@ -600,14 +662,14 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         if (Q || Z) {
             if (sq != s) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
             hipLaunchKernelGGL(ht2_group_wy_kernel, dim3(tcount, 2), dim3(QT), GROUP_LDS_BYTES, sq, n, j0, gsize, tstride, slot,
-                ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.Tb);
+                ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.VTb);
             for (int t = tcount - 1; t >= 0; t--) {
                 int const col0 = j0 + 1 + R2 * t, k = std::min(gsize, n - 1 - col0);
                 if (k <= 0) continue;
                 int const m = std::min(k - 1 + R2, n - col0);
-                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.Tb + (size_t)t * R2 * R2, ws.W1q, ws.W2q, n, m, k,
+                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.VTb + (size_t)t * 2 * R2 * R2, ws.W1q, n, m, k,
                     Q + (size_t)col0 * ldq, ldq);
-                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.Tb + (size_t)(tstride + t) * R2 * R2, ws.W1q, ws.W2q,
+                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, ws.W1q,
                     n, m, k, Z + (size_t)col0 * ldz, ldz);
             }
             if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
