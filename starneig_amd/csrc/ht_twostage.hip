@@ -522,13 +522,14 @@ inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
 inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + 3 * GS - 3) / (3 * GS) + 2); }
 struct Ht2Workspace {
     int n = 0;
-    double *V = nullptr, *VT = nullptr;             // stage 1: RING slots of V and V T^T (2r x r each)
+    double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
     double *W1 = nullptr, *W1q = nullptr;           // GEMM scratch of the two streams
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
     double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
     int maxk = 0;
     bool attr = false;
-    hipEvent_t ready[RING] = {}, used[RING] = {}, tail = nullptr;
+    hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
+    hipEvent_t ready[RING] = {}, used[RING] = {}, used_s[RING] = {}, ready_r[RING] = {}, used_r[RING] = {}, column = nullptr, tail = nullptr;
     hipEvent_t through[MAXSLOT] = {}, applied[MAXSLOT] = {};
     void ensure(int n_)
     {
@@ -540,7 +541,12 @@ struct Ht2Workspace {
             for (int k = 0; k < RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&used[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&used_s[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&ready_r[k], hipEventDisableTiming));
+                SN_HIP_CHECK(hipEventCreateWithFlags(&used_r[k], hipEventDisableTiming));
             }
+            SN_HIP_CHECK(hipEventCreateWithFlags(&column, hipEventDisableTiming));
+            SN_HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
             for (int k = 0; k < MAXSLOT; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&through[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&applied[k], hipEventDisableTiming));
@@ -553,7 +559,7 @@ struct Ht2Workspace {
         n = n_;
         maxk = n / (3 * R2 - 1) + 4;
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
-        alloc(V, (size_t)RING * 2 * R2 * R2); alloc(VT, (size_t)RING * 2 * R2 * R2);
+        alloc(V, (size_t)2 * RING * 2 * R2 * R2); alloc(VT, (size_t)2 * RING * 2 * R2 * R2);
         alloc(W1, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n);
         size_t const refl = (size_t)ht2_nslot(n) * GS * ht2_tstride(n);
         alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
@@ -597,47 +603,56 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     ws.ensure(n);
     int const r = R2;
     if (!sq) sq = s;
-    long slot_count = 0;
-    // a factor slot: wait until `sq` has used its previous content, fill it on `s`, hand it to `sq`
-    auto slot_begin = [&]() {
-        int const k = (int)(slot_count % RING);
-        if (slot_count >= RING && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.used[k], 0));
-        return k;
-    };
-    auto slot_ready = [&](int k) {
-        if (sq == s) return;
-        SN_HIP_CHECK(hipEventRecord(ws.ready[k], s));
-        SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[k], 0));
-    };
-    auto slot_end = [&](int k) {
-        if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.used[k], sq));
-        slot_count++;
-    };
     // ---- stage 1 -----------------------------------------------------------------------------------------------
+    // Three streams.  The QR factorisations of a block column's panels touch the panel's columns only, and nothing
+    // else does until the next block column: they run ahead on `sp`, a ring of factor slots (V, V T^T) between them
+    // and their consumers -- `s` (the trailing columns of A, the rows of B; then the RQ factorisation of the filled
+    // block of B and its applications, from a second ring) and `sq` (Q, Z).  What is left on the chain of a step
+    // is the RQ kernel and eight GEMM launches.
+    hipStream_t const sp = ws.pstream;
+    bool const side = sq != s;
+    long lcount = 0, rcount = 0;
     for (int jc = 0; jc < n - r - 1; jc += r) {
         int const nb = std::min(r, n - jc), top = jc + r;
         std::vector<int> starts;
         for (int i = top; i < n; i += r) starts.push_back(i);
+        // the panel's columns are final once `s` is through the previous block column
+        SN_HIP_CHECK(hipEventRecord(ws.column, s));
+        SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.column, 0));
         auto left_step = [&](int i0, int i1) {
-            int const m = i1 - i0, k = nb, sl = slot_begin();
+            int const m = i1 - i0, k = nb, sl = (int)(lcount % RING);
             double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
-            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, A + (size_t)jc * lda + i0, lda, m, nb, V, VT, 2 * r);
-            slot_ready(sl);
+            if (lcount >= RING) {
+                SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.used_s[sl], 0));
+                if (side && Q) SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.used[sl], 0));
+            }
+            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, sp, A + (size_t)jc * lda + i0, lda, m, nb, V, VT, 2 * r);
+            SN_HIP_CHECK(hipEventRecord(ws.ready[sl], sp));
+            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.ready[sl], 0));
             wy_left(s, V, VT, ws.W1, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
             wy_left(s, V, VT, ws.W1, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
-            if (Q) wy_right(sq, V, VT, ws.W1q, n, m, k, Q + (size_t)i0 * ldq, ldq);
-            slot_end(sl);
+            if (Q) {
+                if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[sl], 0));
+                wy_right(sq, V, VT, ws.W1q, n, m, k, Q + (size_t)i0 * ldq, ldq);
+                if (side) SN_HIP_CHECK(hipEventRecord(ws.used[sl], sq));
+            }
+            SN_HIP_CHECK(hipEventRecord(ws.used_s[sl], s));
+            lcount++;
         };
         auto right_step = [&](int i0, int i1, int mb) {
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
-            int const m = i1 - i0, sl = slot_begin();
-            double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
+            int const m = i1 - i0, sl = (int)(rcount % RING);
+            double *V = ws.V + (size_t)(RING + sl) * 2 * r * r, *VT = ws.VT + (size_t)(RING + sl) * 2 * r * r;
+            if (rcount >= RING && side && Z) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.used_r[sl], 0));
             hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT, 2 * r);
-            slot_ready(sl);
             wy_right(s, V, VT, ws.W1, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
             wy_right(s, V, VT, ws.W1, n, m, mb, A + (size_t)i0 * lda, lda);
-            if (Z) wy_right(sq, V, VT, ws.W1q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
-            slot_end(sl);
+            if (Z) {
+                if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready_r[sl], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[sl], 0)); }
+                wy_right(sq, V, VT, ws.W1q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
+                if (side) SN_HIP_CHECK(hipEventRecord(ws.used_r[sl], sq));
+            }
+            rcount++;
         };
         int const K = (int)starts.size();
         for (int k = K - 1; k >= 1; k--) {
