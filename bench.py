@@ -186,6 +186,31 @@ def lapack_ht_seconds(n):
         return None
 
 
+def two_stage_roofline(n, st):
+    """Stage 2 of the two-stage path (csrc/ht_twostage.hip) streams A and B through the reflector applications
+    of its n^2 / 128 steps: rows p:p1 of A (columns right of the bulge) and B (columns p:n) from the left, columns
+    p:p1 of A (rows 0:p1+64) and B (rows 0:p1) from the right, 16 bytes an entry (read + write).  Algorithmic bytes
+    of those kernels over the whole of stage 2 (reflector generation, 75 us of latency a wavefront, included in the
+    time) against the HBM peak."""
+    import numpy as np
+    r = 64
+    j = np.arange(n - 2, dtype=np.int64)[:, None]
+    t = np.arange((n - 3) // r + 1, dtype=np.int64)[None, :]
+    p = j + 1 + r * t
+    live = p <= n - 2
+    p1 = np.minimum(p + r, n)
+    ln = p1 - p
+    c0 = np.where(t == 0, j, p - r)
+    left = ln * ((n - c0 - 1) + (n - p))
+    right = ln * (np.minimum(p1 + r, n) + p1)
+    nbytes = 16.0 * float(((left + right) * live).sum())
+    stage2_s = (st["rotation_ms"] - st["stage1_ms"]) / 1e3
+    return {"bound": "hbm", "achieved": nbytes / stage2_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": nbytes / stage2_s / 1e9 / 8000.0, "traffic": None,
+            "kernel": "ht2_apply_left_kernel + ht2_apply_right_kernel over stage 2 (%.2f s, %.1f TB algorithmic)"
+                      % (stage2_s, nbytes / 1e12)}
+
+
 def bench_ht(args):
     """Hessenberg-triangular reduction (the step before BASELINE config 5): general
     pencil from the reference test driver's generator (two LCG matrices), n = 12000 by default,
@@ -214,7 +239,7 @@ def bench_ht(args):
     _, cb = S.check_pencil_device(tQ, tB, tZ, tB0, n=n)
     total = sum(times)
     cpu = lapack_ht_seconds(args.cpu_ht_n) if args.cpu_ht_n > 0 else None
-    chain_steps = st["rotations"] / 2            # (0 on the two-stage path, SN_HT_TWOSTAGE=1: no rotation chain)
+    chain_steps = st["rotations"] / 2            # (0 on the two-stage path, the default from n = 2500: no rotation chain)
     two_stage = bool(st.get("two_stage"))
     print(json.dumps({
         "metric": "GFLOP/s Hessenberg-triangular reduction, n=12000 general pencil, 1 MI355X",
@@ -231,8 +256,9 @@ def bench_ht(args):
                    "path": "two-stage Householder (stage 1 %.2f s, stage 2 %.2f s)" % (st["stage1_ms"] / 1e3, (st["rotation_ms"] - st["stage1_ms"]) / 1e3)
                            if two_stage else "rotations (Moler-Stewart order, LDS-resident chain)",
                    "ns_per_chain_rotation": None if two_stage else st["rotation_ms"] * 1e6 / max(chain_steps, 1)},
-        # the step is bound by the dependent chain of n^2/2 column rotations, not by a roofline:
-        "roofline": None if two_stage else {
+        # the rotation path is bound by the dependent chain of n^2/2 column rotations, not by a roofline; stage 2 of
+        # the two-stage path by the HBM traffic of its reflector applications:
+        "roofline": two_stage_roofline(n, st) if two_stage else {
                      "bound": "latency", "achieved": st["rotation_ms"] * 1e6 / max(chain_steps, 1),
                      "peak": 78.0, "unit": "ns per dependent rotation (peak = the bare arithmetic of one "
                      "rotation on one wave, scratch/ht_micro.hip)", "frac": 78.0 / (st["rotation_ms"] * 1e6 / max(chain_steps, 1)),

@@ -923,7 +923,7 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
     }
     // The two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps: a developer switch
     // (SN_HT_TWOSTAGE=1) -- DESIGN.md section 4d has the measurements and why the rotation path stays the default
-    int const two_stage = tuning().ht_two_stage && n >= 3;
+    int const two_stage = n >= 3 && (tuning().ht_two_stage > 0 || (tuning().ht_two_stage < 0 && n >= tuning().ht2_min_n));
     if (two_stage) {
         static hipEvent_t between = nullptr;
         if (!between) SN_HIP_CHECK(hipEventCreate(&between));

@@ -529,6 +529,8 @@ struct Ht2Workspace {
     int maxk = 0;
     bool attr = false;
     hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
+    hipStream_t cstream[3] = {};                    // stage 2: the chains of sweeps beside the caller's stream
+    hipEvent_t lr[4] = {};
     hipEvent_t ready[RING] = {}, used[RING] = {}, used_s[RING] = {}, ready_r[RING] = {}, used_r[RING] = {}, column = nullptr, tail = nullptr;
     hipEvent_t through[MAXSLOT] = {}, applied[MAXSLOT] = {};
     void ensure(int n_)
@@ -547,6 +549,8 @@ struct Ht2Workspace {
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&column, hipEventDisableTiming));
             SN_HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
+            for (int k = 0; k < 3; k++) SN_HIP_CHECK(hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking));
+            for (int k = 0; k < 4; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&lr[k], hipEventDisableTiming));
             for (int k = 0; k < MAXSLOT; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&through[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&applied[k], hipEventDisableTiming));
@@ -671,11 +675,25 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q and Z
     // the last wavefront with a step of group g: its last sweep jl at its last position
     auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return 3 * jl + (n - 3 - jl) / R2; };
+    // The steps of a wavefront are independent; a step depends on its own sweep's previous step and on OLDER sweeps'
+    // steps of the wavefronts before.  The active sweeps are dealt, oldest first, to C chains, each on its own
+    // stream: generation of the reflectors (one workgroup a step, 75 us of latency, no memory traffic to speak of),
+    // then the two wide applications (HBM bound).  The applications of all chains are serialised round robin by
+    // events -- left and right reflectors of different steps meet in common entries --, so what the chains buy is
+    // the generation of one chain under the applications of the others.  A sweep that changes chain (the boundaries
+    // move as old sweeps finish) waits for the whole previous wavefront.
+    int const C = tuning().ht2_chains;
+    hipStream_t const cs[4] = {s, ws.cstream[0], ws.cstream[1], ws.cstream[2]};
+    SN_HIP_CHECK(hipEventRecord(ws.column, s));
+    for (int c = 1; c < C; c++) SN_HIP_CHECK(hipStreamWaitEvent(cs[c], ws.column, 0));
+    hipEvent_t last_ev = nullptr, prev_wave_last = nullptr;
+    hipStream_t last_stream = s;
+    int prev_top[4] = {-1, -1, -1, -1}, prev_cnt[4] = {0, 0, 0, 0};
     auto close_group = [&](int g) {
         int const j0 = g * GS, gsize = std::min(GS, n - 2 - j0), slot = g % nslot;
         int const tcount = (n - 3 - j0) / R2 + 1;
         if (Q || Z) {
-            if (sq != s) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
+            if (sq != last_stream) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], last_stream)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
             hipLaunchKernelGGL(ht2_group_wy_kernel, dim3(tcount, 2), dim3(QT), GROUP_LDS_BYTES, sq, n, j0, gsize, tstride, slot,
                 ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.VTb);
             for (int t = tcount - 1; t >= 0; t--) {
@@ -687,7 +705,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
                 if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, ws.W1q,
                     n, m, k, Z + (size_t)col0 * ldz, ldz);
             }
-            if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
+            if (sq != s || C > 1) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
         }
     };
     for (int tau_idx = 0;; tau_idx++) {
@@ -697,18 +715,31 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         int const jlo = num <= 0 ? 0 : (int)((num + (3 * r - 1) - 1) / (3 * r - 1));
         if (jlo > jhi) { if (tau_idx / 3 >= n - 3) break; else continue; }
         int const count = jhi - jlo + 1;
-        if (count > ws.maxk) return -1;
         for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
-            if (opened >= nslot && sq != s && (Q || Z)) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.applied[opened % nslot], 0));
+            if (opened >= nslot && (sq != s || C > 1) && (Q || Z))
+                for (int c = 0; c < C; c++) SN_HIP_CHECK(hipStreamWaitEvent(cs[c], ws.applied[opened % nslot], 0));
         if (opened - closed > nslot) return -2;
-        Wave2 const w{n, tau_idx, jlo, count, tstride, nslot};
-        hipLaunchKernelGGL(ht2_gen_kernel, dim3(count), dim3(QT), GEN_LDS_BYTES, s, w, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT);
-        hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), count, 2), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT);
-        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), count, 2), dim3(256), 0, s, w,
-            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
+        for (int c = 0; c < C; c++) {
+            int const b0 = jlo + (int)((long)count * c / C), b1 = jlo + (int)((long)count * (c + 1) / C), cnt = b1 - b0;
+            if (cnt <= 0) { prev_cnt[c] = 0; continue; }
+            hipStream_t const st = cs[c];
+            bool const moved = prev_cnt[c] == 0 || (c < C - 1 && b1 > prev_top[c]);
+            if (moved && prev_wave_last && C > 1) SN_HIP_CHECK(hipStreamWaitEvent(st, prev_wave_last, 0));
+            Wave2 const w{n, tau_idx, b0, cnt, tstride, nslot};
+            hipLaunchKernelGGL(ht2_gen_kernel, dim3(cnt), dim3(QT), GEN_LDS_BYTES, st, w, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT);
+            if (last_ev && last_stream != st) SN_HIP_CHECK(hipStreamWaitEvent(st, last_ev, 0));
+            hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), cnt, 2), dim3(256), 0, st, w, A, lda, B, ldb, ws.HV, ws.HT);
+            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), cnt, 2), dim3(256), 0, st, w,
+                RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
+            if (C > 1) { SN_HIP_CHECK(hipEventRecord(ws.lr[c], st)); last_ev = ws.lr[c]; }
+            last_stream = st;
+            prev_top[c] = b1; prev_cnt[c] = cnt;
+        }
+        prev_wave_last = last_ev;
         for (; closed < ngroups && last_wave(closed) <= tau_idx; closed++) close_group(closed);
     }
     for (; closed < ngroups; closed++) close_group(closed);
+    if (last_stream != s && last_ev) SN_HIP_CHECK(hipStreamWaitEvent(s, last_ev, 0));
     if (sq != s) {
         SN_HIP_CHECK(hipEventRecord(ws.tail, sq));
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.tail, 0));

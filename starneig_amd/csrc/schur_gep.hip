@@ -972,6 +972,12 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
                 continue;
             }
         }
+        if (size == 1 && ws.hSub[n + ilo] != 0.0) {
+            // a 1 x 1 block whose B entry is below the infinity threshold of the WHOLE pencil: an infinite
+            // eigenvalue (LAPACK dhgeqz zeroes T(ilast, ilast) against its global BTOL before it deflates a
+            // 1 x 1 block; the window kernels below only know the norm of their window -- |B(i, i)| itself here)
+            SN_HIP_CHECK(hipMemsetAsync(dB + (size_t)ilo * ldB + ilo, 0, sizeof(double), s));
+        }
         if (size <= small_limit) {
             int info = d.small_block(ilo, size, real, imag, beta);
             if (info != 0) { rc = STARNEIG_DID_NOT_CONVERGE; break; }

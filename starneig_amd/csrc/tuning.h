@@ -39,7 +39,10 @@ struct Tuning {
     bool gemm_separate_sum = true;  // SN_GEMM_SEPSUM=0: C += A B with the accumulators STARTING as C (every partial sum rounded at |C|)
     bool gemm_nosplit = false;      // SN_GEMM_NOSPLIT: whole tiles in the last round of workgroups too
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
-    bool ht_two_stage = false;      // SN_HT_TWOSTAGE: Hessenberg-triangular reduction by the two-stage Householder path (ht_twostage.hip)
+    int ht_two_stage = -1;          // SN_HT_TWOSTAGE: the two-stage Householder path of the Hessenberg-triangular reduction (ht_twostage.hip):
+                                    // 1 always, 0 never, unset: from n = ht2_min_n on
+    int ht2_min_n = 2500;           // SN_HT2_MIN_N: (the rotation path is the faster one below n ~ 2000)
+    int ht2_chains = 1;             // SN_HT2_CHAINS: streams the sweeps of its stage 2 are dealt to (1 .. 4; more than one is slower)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 0;              // SN_GEP_REUSE

@@ -46,7 +46,9 @@ Tuning const &tuning()
         t.gemm_kchunk = geti("SN_GEMM_KCHUNK", t.gemm_kchunk);
         t.gemm_nosplit = getb("SN_GEMM_NOSPLIT");
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
-        t.ht_two_stage = getb("SN_HT_TWOSTAGE");
+        t.ht_two_stage = geti("SN_HT_TWOSTAGE", t.ht_two_stage);
+        t.ht2_min_n = geti("SN_HT2_MIN_N", t.ht2_min_n);
+        t.ht2_chains = std::max(1, std::min(4, geti("SN_HT2_CHAINS", t.ht2_chains)));
         t.gep_serial = getb("SN_GEP_SERIAL");
         t.gep_reuse = std::max(0, std::min(8, geti("SN_GEP_REUSE", 0)));
         t.gep_window = geti("SN_GEP_WINDOW", t.gep_window);

@@ -1,8 +1,9 @@
-"""GPU: the two-stage Householder reduction to Hessenberg-triangular form (csrc/ht_twostage.hip; developer switch
-SN_HT_TWOSTAGE=1, read once per process -> child processes).  Round 5 built it to replace the n^2/2 dependent
-column rotations of the rotation path and measured it SLOWER at n <= 8000: it is not the
-product path.  What is asserted here is that it is a correct, backward stable reduction -- exact structure, the
-reference's residual / orthogonality hooks -- also on a singular B, and that QZ accepts its output."""
+"""GPU: the two-stage Householder reduction to Hessenberg-triangular form (csrc/ht_twostage.hip): stage 1 to
+band form by blocked QR / RQ factorisations, stage 2 a chase of Householder bulges with opposite reflectors.  It is
+the product path from n = 2500 on (1.1x the rotation path there, 1.7x at n = 8000); the
+switch SN_HT_TWOSTAGE=1 (read once per process -> child processes) forces it at every size.  Asserted: a correct,
+backward stable reduction -- exact structure, the reference's residual / orthogonality hooks -- at sizes around
+every block boundary, also on a singular B, and QZ on its output."""
 import os
 import subprocess
 import sys
@@ -22,7 +23,7 @@ import starneig_amd as S
 import oracle as O
 from helpers import to_device, to_host, torch_check_pencil
 S.node_init(4, 1, S.NO_MESSAGES)
-for n, singular in ((3, False), (66, False), (129, False), (200, True), (777, False), (2000, False)):
+for n, singular in ((3, False), (4, False), (65, False), (66, False), (129, False), (200, True), (777, False), (2000, False), (4163, False)):
     A0, B0 = O.random_fullpos_pair(n)
     if singular:
         B0[10, :] = 0.0; B0[:, 10] += 0.0      # a rank-deficient B: infinite eigenvalues
