@@ -826,7 +826,7 @@ struct HtWorkspace {
         for (int b = 0; b < 2; b++) { alloc(part[b], (size_t)divceil(n, QROWS) * QP); alloc(prow[b], QNB); }
         for (int b = 0; b < 2; b++) { alloc(Rc2[b], n); alloc(Rs2[b], n); }
         for (int b = 0; b < 3; b++) { alloc(Cc2[b], n); alloc(Cs2[b], n); }
-        if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 16));       // [0] max |b|, [1] error flag of the chain kernels
+        if (!amax) SN_HIP_CHECK(hipMalloc((void **)&amax, 24));       // [0] max |b|, [1] error flag of the chain kernels, [2] max |a| (two-stage path)
         for (int b = 0; b < 2; b++) {
             alloc(rp_beta[b], (size_t)divceil(n, 64) * n); alloc(rp_up[b], (size_t)divceil(n, 64) * n); alloc(rp_alpha[b], divceil(n, 64));
         }
@@ -904,7 +904,7 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
     SN_HIP_CHECK(hipEventRecord(ws.e_cdone, caller));
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_cdone, 0));
     SN_HIP_CHECK(hipEventRecord(ws.ev[0], s));
-    SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 16, s));
+    SN_HIP_CHECK(hipMemsetAsync(ws.amax, 0, 24, s));
     hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dB, ldB, ws.amax);
     hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dB, ldB, ws.amax, 1);
     ht_qr_step(s, ws, n, dA, ldA, dB, ldB, dQ, ldQ, &flops);
@@ -930,8 +930,12 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         // (Q has taken the QR step's update on `s`: the stream of Q and Z starts behind it)
         SN_HIP_CHECK(hipEventRecord(ws.e_scan, s));
         SN_HIP_CHECK(hipStreamWaitEvent(ws.qstream, ws.e_scan, 0));
+        // the Householder kernels of this path take plain sums of squares: A, like B, to max |a| in [1, 2)
+        hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2);
+        hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2, 1);
         int const rc2 = ht_two_stage_device(s, ws.qstream, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
         if (rc2 != 0) return STARNEIG_GENERIC_ERROR;
+        hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2, -1);
         if (stats) { stats[5] = 1.0; }
         SN_HIP_CHECK(hipEventRecord(ws.e_side, s));
         if (stats) {

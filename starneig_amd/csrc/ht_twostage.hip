@@ -284,15 +284,21 @@ __global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int
 constexpr int PANEL_LDS_BYTES = (R2 * LDP + 2 * R2 * R2 + R2 * R2 / 4 + 2 * R2 + 16) * 8;
 
 // ---- stage 2 --------------------------------------------------------------------------------------------------
-// wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - 3 j.  The reflectors of a step are kept
+// wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - LAG j.  The reflectors of a step are kept
 // until the GROUP of its sweep (GS consecutive sweeps) has gone through: slot (j / GS) mod nslot of the store,
 // entry (j mod GS) * tstride + t there.
 constexpr int GS = 64;
+// Sweep j is at position t = tau - LAG j in wavefront tau.  LAG = 2: the steps (j, t) and (j - 1, t + 2) of one
+// wavefront are 127 rows / columns apart (reflectors: 64), and the one entry both touch -- A(p + 127, p + 63), read
+// by the older sweep's generation, rewritten by the younger sweep's right application -- is read first, as in the
+// sweep-by-sweep order, because generation precedes the applications of a wavefront.  (LAG = 1 is wrong, 3 wasted
+// a third of the wavefronts: scratch/ht2_lag.py, tests/test_ht_twostage_prototype.py.)
+constexpr int LAG = 2;
 struct Wave2 { int n, tau_idx, jlo, count, tstride, nslot; };
 
 __device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, int &c0, int &ridx)
 {
-    int const j = w.jlo + k, t = w.tau_idx - 3 * j;
+    int const j = w.jlo + k, t = w.tau_idx - LAG * j;
     if (k >= w.count || t < 0 || j > w.n - 3) return false;
     p = j + 1 + t * R2;
     if (p > w.n - 2) return false;
@@ -517,16 +523,15 @@ constexpr int GROUP_LDS_BYTES = (R2 * LDVS + 2 * R2 * R2 + R2 * R2 / 4 + R2 + 16
 constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
 constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
 inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
-// a group is in the chase for 3 (GS - 1) + tstride wavefronts, the next one starts 3 GS wavefronts after it; one
+// a group is in the chase for LAG (GS - 1) + tstride wavefronts, the next one starts LAG GS wavefronts after it; one
 // more slot for the group whose blocks the second stream is still applying
-inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + 3 * GS - 3) / (3 * GS) + 2); }
+inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + LAG * GS - LAG) / (LAG * GS) + 2); }
 struct Ht2Workspace {
     int n = 0;
     double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
     double *W1 = nullptr, *W1q = nullptr;           // GEMM scratch of the two streams
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
     double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
-    int maxk = 0;
     bool attr = false;
     hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
     hipStream_t cstream[3] = {};                    // stage 2: the chains of sweeps beside the caller's stream
@@ -561,7 +566,6 @@ struct Ht2Workspace {
         if (n_ <= n) return;
         release();
         n = n_;
-        maxk = n / (3 * R2 - 1) + 4;
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
         alloc(V, (size_t)2 * RING * 2 * R2 * R2); alloc(VT, (size_t)2 * RING * 2 * R2 * R2);
         alloc(W1, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n);
@@ -674,7 +678,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     int const tstride = ht2_tstride(n), nslot = ht2_nslot(n), ngroups = (n - 2 + GS - 1) / GS;
     int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q and Z
     // the last wavefront with a step of group g: its last sweep jl at its last position
-    auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return 3 * jl + (n - 3 - jl) / R2; };
+    auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return LAG * jl + (n - 3 - jl) / R2; };
     // The steps of a wavefront are independent; a step depends on its own sweep's previous step and on OLDER sweeps'
     // steps of the wavefronts before.  The active sweeps are dealt, oldest first, to C chains, each on its own
     // stream: generation of the reflectors (one workgroup a step, 75 us of latency, no memory traffic to speak of),
@@ -709,11 +713,11 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         }
     };
     for (int tau_idx = 0;; tau_idx++) {
-        int const jhi = std::min(tau_idx / 3, n - 3);
-        // position t = tau_idx - 3 j must satisfy j + 1 + t r <= n - 2
+        int const jhi = std::min(tau_idx / LAG, n - 3);
+        // position t = tau_idx - LAG j must satisfy j + 1 + t r <= n - 2
         long const num = (long)tau_idx * r - (n - 3);
-        int const jlo = num <= 0 ? 0 : (int)((num + (3 * r - 1) - 1) / (3 * r - 1));
-        if (jlo > jhi) { if (tau_idx / 3 >= n - 3) break; else continue; }
+        int const jlo = num <= 0 ? 0 : (int)((num + (LAG * r - 1) - 1) / (LAG * r - 1));
+        if (jlo > jhi) { if (tau_idx / LAG >= n - 3) break; else continue; }
         int const count = jhi - jlo + 1;
         for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
             if (opened >= nslot && (sq != s || C > 1) && (Q || Z))

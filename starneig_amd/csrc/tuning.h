@@ -41,7 +41,7 @@ struct Tuning {
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
     int ht_two_stage = -1;          // SN_HT_TWOSTAGE: the two-stage Householder path of the Hessenberg-triangular reduction (ht_twostage.hip):
                                     // 1 always, 0 never, unset: from n = ht2_min_n on
-    int ht2_min_n = 2500;           // SN_HT2_MIN_N: (the rotation path is the faster one below n ~ 2000)
+    int ht2_min_n = 1500;           // SN_HT2_MIN_N: (the rotation path is the faster one up to n ~ 1000)
     int ht2_chains = 1;             // SN_HT2_CHAINS: streams the sweeps of its stage 2 are dealt to (1 .. 4; more than one is slower)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL

@@ -1,6 +1,6 @@
 """GPU: the two-stage Householder reduction to Hessenberg-triangular form (csrc/ht_twostage.hip): stage 1 to
 band form by blocked QR / RQ factorisations, stage 2 a chase of Householder bulges with opposite reflectors.  It is
-the product path from n = 2500 on (1.1x the rotation path there, 1.7x at n = 8000); the
+the product path from n = 1500 on (1.4x the rotation path at n = 2500, 2x at n = 8000); the
 switch SN_HT_TWOSTAGE=1 (read once per process -> child processes) forces it at every size.  Asserted: a correct,
 backward stable reduction -- exact structure, the reference's residual / orthogonality hooks -- at sizes around
 every block boundary, also on a singular B, and QZ on its output."""
@@ -44,6 +44,18 @@ for n, singular in ((3, False), (4, False), (65, False), (66, False), (129, Fals
         assert rc == 0 and O.check_gep_schur_form(to_host(tA), to_host(tB)) == 0
         ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
         assert max(ra, oq, oz) < 500.0
+# badly scaled A and B (exact powers of two): the path works on both scaled to [1, 2), the results scale back
+n = 300
+A0, B0 = O.random_fullpos_pair(n)
+out = []
+for sa, sb in ((1.0, 1.0), (2.0 ** -600, 2.0 ** 500)):
+    tA, tB = to_device(np.asfortranarray(A0 * sa)), to_device(np.asfortranarray(B0 * sb))
+    tQ, tZ = to_device(O.identity(n)), to_device(O.identity(n))
+    rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+    assert rc == 0 and st["two_stage"]
+    out.append((to_host(tA)[:n] / sa, to_host(tB)[:n] / sb, to_host(tQ)[:n], to_host(tZ)[:n]))
+for x, y in zip(*out):          # (equal up to the run-to-run rounding of the split-K sums in the QR step)
+    assert np.all(np.isfinite(y)) and np.abs(x - y).max() <= 1e-8 * np.abs(x).max()
 S.node_finalize()
 print("OK")
 """

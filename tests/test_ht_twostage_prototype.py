@@ -36,3 +36,32 @@ def test_two_stage_reduction_is_backward_stable(n, r, singular):
     assert np.linalg.norm(Z.T @ Z - np.eye(n)) <= 100 * U * np.sqrt(n)
     # the chase of stage 2: ~ n^2 / (2 r) steps of one left and one right reflector of length <= r
     assert abs(len(log) - n * n / (2.0 * r)) <= 0.35 * n * n / (2.0 * r)
+
+
+# ---- the order the device code runs stage 2 in ------------------------------------------------------------------
+spec2 = importlib.util.spec_from_file_location("ht2_lag", os.path.join(ROOT, "scratch", "ht2_lag.py"))
+L = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(L)
+
+
+@pytest.mark.parametrize("n,r,singular", [(60, 4, False), (97, 8, True), (131, 8, False)])
+def test_stage_2_in_wavefronts_of_lag_2(n, r, singular):
+    """csrc/ht_twostage.hip runs the steps (sweep j, position t) with t + 2 j = tau together: all reflectors from the
+    state at the start of the wavefront, then all left, then all right applications.  That order must give a correct
+    reduction (lag 2 does; lag 1 -- neighbouring sweeps one block apart -- must not, or this test checks nothing)."""
+    def run(lag):
+        rng = np.random.default_rng(n)
+        A0 = rng.standard_normal((n, n)); B0 = np.triu(rng.standard_normal((n, n)))
+        if singular:
+            B0[10, 10] = 0.0; B0[50, 50] = 0.0
+        A, B = A0.copy(), B0.copy(); Q = np.eye(n); Z = np.eye(n)
+        P.stage1(A, B, Q, Z, r)
+        waves = L.stage2_wavefronts(A, B, Q, Z, r, lag)
+        return waves, np.abs(np.tril(A, -2)).max(), np.abs(np.tril(B, -1)).max(), \
+            np.linalg.norm(Q @ A @ Z.T - A0) / np.linalg.norm(A0), np.linalg.norm(Q @ B @ Z.T - B0) / np.linalg.norm(B0)
+    w2, la, lb, ra, rb = run(2)
+    assert la == 0.0 and lb == 0.0 and ra <= 100 * U and rb <= 100 * U
+    w3, la3, lb3, ra3, rb3 = run(3)
+    assert la3 == 0.0 and ra3 <= 100 * U and w2 < 0.75 * w3
+    _, _, _, ra1, _ = run(1)
+    assert ra1 > 1e6 * U
