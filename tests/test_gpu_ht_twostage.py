@@ -44,6 +44,35 @@ for n, singular in ((3, False), (4, False), (65, False), (66, False), (129, Fals
         assert rc == 0 and O.check_gep_schur_form(to_host(tA), to_host(tB)) == 0
         ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
         assert max(ra, oq, oz) < 500.0
+# the product's own choice of path at n = 1600 (no switch in this child's tuning: forced on; see the parent test
+# below for the default): (H, T) without Q and Z, and accumulation into given orthogonal Q0, Z0
+n = 1600
+A0, B0 = O.random_fullpos_pair(n)
+rng = np.random.default_rng(7)
+Q0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, n)))[0]); Z0 = np.asfortranarray(np.linalg.qr(rng.standard_normal((n, n)))[0])
+tA, tB = to_device(A0), to_device(B0)
+tQ, tZ = to_device(O.identity(n)), to_device(O.identity(n))
+rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+assert rc == 0 and st["two_stage"]
+H1, T1 = to_host(tA)[:n], to_host(tB)[:n]
+tA, tB = to_device(A0), to_device(B0)
+rc, st = S.hessenberg_triangular_device(tA, tB, None, None, n=n)
+assert rc == 0 and st["two_stage"]
+H2, T2 = to_host(tA)[:n], to_host(tB)[:n]
+assert np.abs(H1 - H2).max() <= 1e-8 * np.abs(H1).max() and np.abs(T1 - T2).max() <= 1e-8 * np.abs(T1).max()
+tA, tB = to_device(A0), to_device(B0)
+tQ, tZ = to_device(Q0), to_device(Z0)
+rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+assert rc == 0
+# Q <- Q0 U1, Z <- Z0 U2 with U1^T A0 U2 = H: (Q0^T Q) H (Z0^T Z)^T = A0
+Q, Z, H, T = to_host(tQ)[:n], to_host(tZ)[:n], to_host(tA)[:n], to_host(tB)[:n]
+U1, U2 = Q0[:n].T @ Q, Z0[:n].T @ Z
+u = 2.0 ** -52
+ra = np.linalg.norm(U1 @ H @ U2.T - A0[:n]) / np.linalg.norm(A0[:n]) / u
+rb = np.linalg.norm(U1 @ T @ U2.T - B0[:n]) / np.linalg.norm(B0[:n]) / u
+oq = np.linalg.norm(Q.T @ Q - np.eye(n)) / u / np.sqrt(n)
+print(f"n={n} given Q0, Z0: residuals {ra:.1f} / {rb:.1f} u, orthogonality of Q {oq:.1f} u", flush=True)
+assert max(ra, rb) < 500.0 and oq < 500.0
 # badly scaled A and B (exact powers of two): the path works on both scaled to [1, 2), the results scale back
 n = 300
 A0, B0 = O.random_fullpos_pair(n)
@@ -59,6 +88,28 @@ for x, y in zip(*out):          # (equal up to the run-to-run rounding of the sp
 S.node_finalize()
 print("OK")
 """
+
+
+def test_default_path_by_size(tmp_path):
+    """without any switch: rotations below n = 1500, the two-stage path from there on"""
+    code = r"""
+import os, sys
+import torch
+torch.cuda.set_device(0); torch.zeros(1, device="cuda")
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import starneig_amd as S
+S.node_init(1, 1, S.NO_MESSAGES)
+for n in (1499, 1500):
+    tA, tB = S.device_matrix(n), S.device_matrix(n)
+    S.lcg_fill_device(tA, n, n, seed=2019); S.lcg_fill_device(tB, n, n, seed=77)
+    rc, st = S.hessenberg_triangular_device(tA, tB, None, None, n=n)
+    assert rc == 0 and st["two_stage"] == (n >= 1500), (n, st)
+S.node_finalize()
+print("OK")
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("STARNEIG_AMD_TUNING", "SN_HT_TWOSTAGE", "SN_HT2_MIN_N")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
 
 
 def test_two_stage_reduction_is_a_correct_hessenberg_triangular_reduction():
