@@ -123,8 +123,12 @@ starneig_error_t starneig_amd_gep_schur_device(
     struct starneig_schur_conf *conf, void *stream, double *stats);
 
 /* Device-resident twin of starneig_GEP_SM_HessenbergTriangular (wrappers/lapack.c:45-176):
- * general (dA, dB) -> (H, T); dQ / dZ may be NULL.  stats (may be NULL, double[8]): [0] total ms,
- * [1] QR step ms, [2] rotation step ms, [3] executed GEMM flops, [4] rotations applied. */
+ * general (dA, dB) -> (H, T); dQ / dZ may be NULL.  Below n = 1500 the rotations of LAPACK dgghrd (results agree
+ * with dgeqrf + dormqr + dgghrd up to rounding), from there on a two-stage Householder reduction (band form by
+ * blocked QR / RQ, then a bulge chase; backward stable, no LAPACK counterpart entry by entry).  stats (may be NULL,
+ * double[8]): [0] total ms, [1] QR step ms, [2] ms of the step after it (rotations, or both stages), [3] executed
+ * GEMM flops of the QR step, [4] rotations applied (0 on the two-stage path), [5] 1 = two-stage path, [6] its
+ * stage 1 ms. */
 starneig_error_t starneig_amd_hessenberg_triangular_device(
     int n, double *dA, int ldA, double *dB, int ldB, double *dQ, int ldQ, double *dZ, int ldZ,
     void *stream, double *stats);
