@@ -469,7 +469,8 @@ def secondary_in_child():
     """The secondary workloads run in a child process of their own (started here, relayed, never exec'ed):
     the stream set-up the Hessenberg-triangular reduction is tuned for is the one of a fresh process -- after
     the Schur and QZ legs have created their ~20 priority streams the same reduction runs at half the rate
-    (the runtime multiplexes streams onto a few hardware queues)."""
+    (the runtime multiplexes streams onto a few hardware queues).  The caller starts it before it creates its own
+    HIP context, for the same reason."""
     import subprocess
     proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "secondary"],
                           capture_output=True, text=True, timeout=900)
@@ -547,14 +548,18 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s)"
     sharded = world > 1 or args.force_sharded
+    # The secondary workloads (not part of `value`) run in a child process BEFORE this process touches the GPU: the
+    # streams a live process holds are hardware queues the child's streams are multiplexed with -- the launch-bound
+    # Hessenberg-triangular reduction measured 6.05 s at n = 8000 beside this process's idle streams, 5.45 s alone.
+    secondary = secondary_in_child() if (world == 1 and args.secondary and not sharded) else None
+
+    import torch
+    import torch.distributed as dist
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
@@ -775,7 +780,7 @@ def main():
         if world == 1 and args.secondary and not sharded:
             # driver-timed secondary workloads (not part of `value`): BASELINE config 5 and the same
             # size on a well-conditioned pencil, where the QZ sweeps -- not the host AED -- do the work
-            out["secondary"] = secondary_in_child()
+            out["secondary"] = secondary
 
     if sharded:
         from starneig_amd import distributed as _D

@@ -18,6 +18,7 @@
 #include "tuning.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <vector>
 
 namespace sn {
@@ -520,6 +521,134 @@ __global__ __launch_bounds__(QT) void ht2_group_wy_kernel(int n, int j0, int gsi
 }
 constexpr int GROUP_LDS_BYTES = (R2 * LDVS + 2 * R2 * R2 + R2 * R2 / 4 + R2 + 16) * 8;
 
+// ---- compact-WY applications: one kernel for up to two targets -----------------------------------------------
+// Stage 1 is bound by the HOST: 24 runtime calls a step (kernel launches, event records and waits) at 9 us each are
+// its 1.64 s at n = 8000 (13 us each once a QZ run has left its streams and events in the process: 2.24 s).  So the
+// two GEMM launches of an application (W = V^T X, X -= (V T^T) W) are one kernel -- a workgroup keeps its slab of X in
+// LDS, forms W there and writes the slab once; V, then V T^T, through the same LDS buffer; the products on the matrix
+// core -- and the two matrices that take the same factors go in one launch (blockIdx.y).
+constexpr int WY_T = 512, WY_SLAB = 32;
+constexpr int WY_LDV = 2 * R2 + 1, WY_LDW = R2 + 1, WY_LDR = WY_SLAB + 1;
+constexpr int WY_LEFT_LDS = (R2 * WY_LDV + WY_SLAB * WY_LDV + WY_SLAB * WY_LDW) * 8;
+constexpr int WY_RIGHT_LDS = (R2 * WY_LDV + 2 * R2 * WY_LDR + R2 * WY_LDR) * 8;
+struct WyTargets { double *X[2]; int ld[2]; int extent[2]; };      // extent: columns (left) / rows (right)
+
+// a factor (2 r x r, leading dimension 2 r, zero beyond m rows and k columns) into registers -- every load in flight
+// at once, and V T^T on its way while W is still being formed from V -- and from there into LDS
+constexpr int WY_FREG = 2 * R2 * R2 / WY_T;
+__device__ __forceinline__ void wy_fetch_factor(double (&f)[WY_FREG], double const *__restrict__ V, int m, int k)
+{
+    #pragma unroll
+    for (int u = 0; u < WY_FREG; u++) {
+        int const e = threadIdx.x + u * WY_T, r = e % (2 * R2), c = e / (2 * R2);
+        f[u] = (r < m && c < k) ? V[(size_t)c * 2 * R2 + r] : 0.0;
+    }
+}
+__device__ __forceinline__ void wy_store_factor(double *Vs, double const (&f)[WY_FREG])
+{
+    #pragma unroll
+    for (int u = 0; u < WY_FREG; u++) {
+        int const e = threadIdx.x + u * WY_T, r = e % (2 * R2), c = e / (2 * R2);
+        Vs[c * WY_LDV + r] = f[u];
+    }
+}
+
+// X (m x ncols, m <= 2 r) <- X - (V T^T) (V^T X); blockIdx.x: slab of WY_SLAB columns, blockIdx.y: target
+__global__ __launch_bounds__(WY_T) void ht2_wy_left_kernel(double const *__restrict__ V, double const *__restrict__ VT, int m, int k,
+    WyTargets tg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Vs = lds, *Xs = Vs + R2 * WY_LDV, *Ws = Xs + WY_SLAB * WY_LDV;
+    int const tid = threadIdx.x, wave = tid >> 6, l = tid & 63, q = l & 15, kk = l >> 4, z = blockIdx.y;
+    int const ncols = tg.extent[z], ldx = tg.ld[z], c0 = blockIdx.x * WY_SLAB;
+    if (c0 >= ncols) return;
+    double *X = tg.X[z];
+    int const nc = min(WY_SLAB, ncols - c0);
+    double f[WY_FREG], xr[WY_SLAB * 2 * R2 / WY_T];
+    wy_fetch_factor(f, V, m, k);
+    #pragma unroll
+    for (int u = 0; u < WY_SLAB * 2 * R2 / WY_T; u++) {
+        int const e = tid + u * WY_T, r = e % (2 * R2), c = e / (2 * R2);
+        xr[u] = (r < m && c < nc) ? X[(size_t)(c0 + c) * ldx + r] : 0.0;
+    }
+    wy_store_factor(Vs, f);
+    #pragma unroll
+    for (int u = 0; u < WY_SLAB * 2 * R2 / WY_T; u++) { int const e = tid + u * WY_T; Xs[(e / (2 * R2)) * WY_LDV + e % (2 * R2)] = xr[u]; }
+    wy_fetch_factor(f, VT, m, k);
+    __syncthreads();
+    {   // W (r x slab) = V^T X: 4 x 2 tiles, one per wave
+        int const ti = wave & 3, tj = wave >> 2;
+        d4v const d = wave_tile(2 * R2, [&](int i, int kr) { return Vs[(16 * ti + i) * WY_LDV + kr]; },
+                                        [&](int kr, int j) { return Xs[(16 * tj + j) * WY_LDV + kr]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) Ws[(16 * tj + q) * WY_LDW + 16 * ti + kk + 4 * reg] = d[reg];
+    }
+    __syncthreads();
+    wy_store_factor(Vs, f);
+    __syncthreads();
+    // X -= (V T^T) W: 8 x 2 tiles, two per wave
+    for (int tile = wave; tile < 16; tile += WY_T / 64) {
+        int const ti = tile & 7, tj = tile >> 3;
+        d4v const d = wave_tile(R2, [&](int i, int kr) { return Vs[kr * WY_LDV + 16 * ti + i]; },
+                                    [&](int kr, int j) { return Ws[(16 * tj + j) * WY_LDW + kr]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) Xs[(16 * tj + q) * WY_LDV + 16 * ti + kk + 4 * reg] -= d[reg];
+    }
+    __syncthreads();
+    for (int e = tid; e < WY_SLAB * 2 * R2; e += WY_T) {
+        int const r = e % (2 * R2), c = e / (2 * R2);
+        if (r < m && c < nc) X[(size_t)(c0 + c) * ldx + r] = Xs[c * WY_LDV + r];
+    }
+}
+
+// X (nrows x m, m <= 2 r) <- X - (X V) (V T^T)^T; blockIdx.x: slab of WY_SLAB rows, blockIdx.y: target
+__global__ __launch_bounds__(WY_T) void ht2_wy_right_kernel(double const *__restrict__ V, double const *__restrict__ VT, int m, int k,
+    WyTargets tg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *Vs = lds, *Xs = Vs + R2 * WY_LDV, *Ws = Xs + 2 * R2 * WY_LDR;       // Xs[c][r], Ws[kk][r]
+    int const tid = threadIdx.x, wave = tid >> 6, l = tid & 63, q = l & 15, kk = l >> 4, z = blockIdx.y;
+    int const nrows = tg.extent[z], ldx = tg.ld[z], r0 = blockIdx.x * WY_SLAB;
+    if (r0 >= nrows) return;
+    double *X = tg.X[z];
+    int const nr = min(WY_SLAB, nrows - r0);
+    double f[WY_FREG], xr[2 * R2 * WY_SLAB / WY_T];
+    wy_fetch_factor(f, V, m, k);
+    #pragma unroll
+    for (int u = 0; u < 2 * R2 * WY_SLAB / WY_T; u++) {
+        int const e = tid + u * WY_T, r = e % WY_SLAB, c = e / WY_SLAB;
+        xr[u] = (r < nr && c < m) ? X[(size_t)c * ldx + r0 + r] : 0.0;
+    }
+    wy_store_factor(Vs, f);
+    #pragma unroll
+    for (int u = 0; u < 2 * R2 * WY_SLAB / WY_T; u++) { int const e = tid + u * WY_T; Xs[(e / WY_SLAB) * WY_LDR + e % WY_SLAB] = xr[u]; }
+    wy_fetch_factor(f, VT, m, k);
+    __syncthreads();
+    {   // W (slab x r) = X V: 2 x 4 tiles, one per wave
+        int const ti = wave & 1, tj = wave >> 1;
+        d4v const d = wave_tile(2 * R2, [&](int i, int kr) { return Xs[kr * WY_LDR + 16 * ti + i]; },
+                                        [&](int kr, int j) { return Vs[(16 * tj + j) * WY_LDV + kr]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) Ws[(16 * tj + q) * WY_LDR + 16 * ti + kk + 4 * reg] = d[reg];
+    }
+    __syncthreads();
+    wy_store_factor(Vs, f);
+    __syncthreads();
+    // X -= W (V T^T)^T: 2 x 8 tiles, two per wave
+    for (int tile = wave; tile < 16; tile += WY_T / 64) {
+        int const ti = tile & 1, tj = tile >> 1;
+        d4v const d = wave_tile(R2, [&](int i, int kr) { return Ws[kr * WY_LDR + 16 * ti + i]; },
+                                    [&](int kr, int j) { return Vs[kr * WY_LDV + 16 * tj + j]; });
+        #pragma unroll
+        for (int reg = 0; reg < 4; reg++) Xs[(16 * tj + q) * WY_LDR + 16 * ti + kk + 4 * reg] -= d[reg];
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * R2 * WY_SLAB; e += WY_T) {
+        int const r = e % WY_SLAB, c = e / WY_SLAB;
+        if (r < nr && c < m) X[(size_t)c * ldx + r0 + r] = Xs[c * WY_LDR + r];
+    }
+}
+
 constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
 constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
 inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
@@ -529,7 +658,6 @@ inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + LAG * G
 struct Ht2Workspace {
     int n = 0;
     double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
-    double *W1 = nullptr, *W1q = nullptr;           // GEMM scratch of the two streams
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
     double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
     bool attr = false;
@@ -545,6 +673,8 @@ struct Ht2Workspace {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_LEFT_LDS));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_right_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_RIGHT_LDS));
             for (int k = 0; k < RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&used[k], hipEventDisableTiming));
@@ -553,7 +683,15 @@ struct Ht2Workspace {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&used_r[k], hipEventDisableTiming));
             }
             SN_HIP_CHECK(hipEventCreateWithFlags(&column, hipEventDisableTiming));
-            SN_HIP_CHECK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
+            {   // a stream created with a CU mask gets a hardware queue of its own (the runtime multiplexes the plain
+                // streams of one priority onto four queues, whoever created them -- after a QZ run in the same process
+                // stage 1 took 2.24 s instead of 1.64 s at n = 8000 with a plain stream here)
+                hipDeviceProp_t prop; int dev = 0;
+                SN_HIP_CHECK(hipGetDevice(&dev)); SN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                int const words = (prop.multiProcessorCount + 31) / 32;
+                std::vector<uint32_t> mask(words, 0xffffffffu);
+                SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&pstream, words, mask.data()));
+            }
             for (int k = 0; k < 3; k++) SN_HIP_CHECK(hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking));
             for (int k = 0; k < 4; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&lr[k], hipEventDisableTiming));
             for (int k = 0; k < MAXSLOT; k++) {
@@ -568,33 +706,40 @@ struct Ht2Workspace {
         n = n_;
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
         alloc(V, (size_t)2 * RING * 2 * R2 * R2); alloc(VT, (size_t)2 * RING * 2 * R2 * R2);
-        alloc(W1, (size_t)R2 * n); alloc(W1q, (size_t)R2 * n);
         size_t const refl = (size_t)ht2_nslot(n) * GS * ht2_tstride(n);
         alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
         alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(VTb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2);
     }
     void release()
     {
-        double **all[] = {&V, &VT, &W1, &W1q, &HV, &HT, &GV, &GT, &Vb, &VTb};
+        double **all[] = {&V, &VT, &HV, &HT, &GV, &GT, &Vb, &VTb};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
 };
 Ht2Workspace g_ht2;
 
-// X (m x ncols) <- (I - V T V^T)^T X = X - (V T^T) (V^T X)
-void wy_left(hipStream_t s, double const *V, double const *VT, double *W1, int m, int k, int ncols, double *X, int ldx)
+// X_z (m x ncols_z) <- (I - V T V^T)^T X_z for one or two matrices (X1 may be NULL)
+void wy_left(hipStream_t s, double const *V, double const *VT, int m, int k, double *X0, int ld0, int ncols0,
+    double *X1 = nullptr, int ld1 = 0, int ncols1 = 0)
 {
-    if (ncols <= 0 || k <= 0) return;
-    dgemm(s, 'T', 'N', k, ncols, m, 1.0, V, 2 * R2, X, ldx, 0.0, W1, R2);
-    dgemm(s, 'N', 'N', m, ncols, k, -1.0, VT, 2 * R2, W1, R2, 1.0, X, ldx);
+    if (k <= 0) return;
+    if (!X1) ncols1 = 0;
+    int const widest = std::max(ncols0, ncols1);
+    if (widest <= 0) return;
+    hipLaunchKernelGGL(ht2_wy_left_kernel, dim3(divceil(widest, WY_SLAB), X1 ? 2 : 1), dim3(WY_T), WY_LEFT_LDS, s, V, VT, m, k,
+        WyTargets{{X0, X1}, {ld0, ld1}, {ncols0, ncols1}});
 }
-// X (nrows x m) <- X (I - V T V^T) = X - (X V) (V T^T)^T
-void wy_right(hipStream_t s, double const *V, double const *VT, double *W1, int nrows, int m, int k, double *X, int ldx)
+// X_z (nrows_z x m) <- X_z (I - V T V^T)
+void wy_right(hipStream_t s, double const *V, double const *VT, int m, int k, double *X0, int ld0, int nrows0,
+    double *X1 = nullptr, int ld1 = 0, int nrows1 = 0)
 {
-    if (nrows <= 0 || k <= 0) return;
-    dgemm(s, 'N', 'N', nrows, k, m, 1.0, X, ldx, V, 2 * R2, 0.0, W1, nrows);
-    dgemm(s, 'N', 'T', nrows, m, k, -1.0, W1, nrows, VT, 2 * R2, 1.0, X, ldx);
+    if (k <= 0) return;
+    if (!X1) nrows1 = 0;
+    int const tallest = std::max(nrows0, nrows1);
+    if (tallest <= 0) return;
+    hipLaunchKernelGGL(ht2_wy_right_kernel, dim3(divceil(tallest, WY_SLAB), X1 ? 2 : 1), dim3(WY_T), WY_RIGHT_LDS, s, V, VT, m, k,
+        WyTargets{{X0, X1}, {ld0, ld1}, {nrows0, nrows1}});
 }
 
 } // namespace
@@ -614,12 +759,17 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     // ---- stage 1 -----------------------------------------------------------------------------------------------
     // Three streams.  The QR factorisations of a block column's panels touch the panel's columns only, and nothing
     // else does until the next block column: they run ahead on `sp`, a ring of factor slots (V, V T^T) between them
-    // and their consumers -- `s` (the trailing columns of A, the rows of B; then the RQ factorisation of the filled
-    // block of B and its applications, from a second ring) and `sq` (Q, Z).  What is left on the chain of a step
-    // is the RQ kernel and eight GEMM launches.
+    // and their consumers -- `s` (the trailing columns of A and the rows of B in one launch; then the RQ
+    // factorisation of the filled block of B and its application to B and A, from a second ring) and `sq` (Q, Z).
+    // The host is the bottleneck here, so the calls are counted: a consumer tells the producer of a ring that slots
+    // are free again once per EPOCH steps, not per step (two events per ring and consumer, alternating).
     hipStream_t const sp = ws.pstream;
     bool const side = sq != s;
     long lcount = 0, rcount = 0;
+    constexpr int EPOCH = RING / 2;
+    // consumer side: after step i of a ring; producer side: before step L of that ring
+    auto epoch_record = [&](hipEvent_t *ev, long i, hipStream_t st) { if (i % EPOCH == EPOCH - 1) SN_HIP_CHECK(hipEventRecord(ev[(i / EPOCH) % 2], st)); };
+    auto epoch_wait = [&](hipEvent_t *ev, long L, hipStream_t st) { if (L >= RING && L % EPOCH == 0) SN_HIP_CHECK(hipStreamWaitEvent(st, ev[(L / EPOCH) % 2], 0)); };
     for (int jc = 0; jc < n - r - 1; jc += r) {
         int const nb = std::min(r, n - jc), top = jc + r;
         std::vector<int> starts;
@@ -630,35 +780,32 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         auto left_step = [&](int i0, int i1) {
             int const m = i1 - i0, k = nb, sl = (int)(lcount % RING);
             double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
-            if (lcount >= RING) {
-                SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.used_s[sl], 0));
-                if (side && Q) SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.used[sl], 0));
-            }
+            epoch_wait(ws.used_s, lcount, sp);
+            if (side && Q) epoch_wait(ws.used, lcount, sp);
             hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, sp, A + (size_t)jc * lda + i0, lda, m, nb, V, VT, 2 * r);
             SN_HIP_CHECK(hipEventRecord(ws.ready[sl], sp));
             SN_HIP_CHECK(hipStreamWaitEvent(s, ws.ready[sl], 0));
-            wy_left(s, V, VT, ws.W1, m, k, n - jc - nb, A + (size_t)(jc + nb) * lda + i0, lda);
-            wy_left(s, V, VT, ws.W1, m, k, n - i0, B + (size_t)i0 * ldb + i0, ldb);
+            wy_left(s, V, VT, m, k, A + (size_t)(jc + nb) * lda + i0, lda, n - jc - nb, B + (size_t)i0 * ldb + i0, ldb, n - i0);
             if (Q) {
                 if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[sl], 0));
-                wy_right(sq, V, VT, ws.W1q, n, m, k, Q + (size_t)i0 * ldq, ldq);
-                if (side) SN_HIP_CHECK(hipEventRecord(ws.used[sl], sq));
+                wy_right(sq, V, VT, m, k, Q + (size_t)i0 * ldq, ldq, n);
+                if (side) epoch_record(ws.used, lcount, sq);
             }
-            SN_HIP_CHECK(hipEventRecord(ws.used_s[sl], s));
+            epoch_record(ws.used_s, lcount, s);
             lcount++;
         };
         auto right_step = [&](int i0, int i1, int mb) {
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
             int const m = i1 - i0, sl = (int)(rcount % RING);
             double *V = ws.V + (size_t)(RING + sl) * 2 * r * r, *VT = ws.VT + (size_t)(RING + sl) * 2 * r * r;
-            if (rcount >= RING && side && Z) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.used_r[sl], 0));
+            if (side && Z) epoch_wait(ws.used_r, rcount, s);
             hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT, 2 * r);
-            wy_right(s, V, VT, ws.W1, i1 - mb, m, mb, B + (size_t)i0 * ldb, ldb);
-            wy_right(s, V, VT, ws.W1, n, m, mb, A + (size_t)i0 * lda, lda);
+            if (Z && side) SN_HIP_CHECK(hipEventRecord(ws.ready_r[sl], s));
+            wy_right(s, V, VT, m, mb, A + (size_t)i0 * lda, lda, n, B + (size_t)i0 * ldb, ldb, i1 - mb);
             if (Z) {
-                if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready_r[sl], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[sl], 0)); }
-                wy_right(sq, V, VT, ws.W1q, n, m, mb, Z + (size_t)i0 * ldz, ldz);
-                if (side) SN_HIP_CHECK(hipEventRecord(ws.used_r[sl], sq));
+                if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[sl], 0));
+                wy_right(sq, V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n);
+                if (side) epoch_record(ws.used_r, rcount, sq);
             }
             rcount++;
         };
@@ -704,10 +851,10 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
                 int const col0 = j0 + 1 + R2 * t, k = std::min(gsize, n - 1 - col0);
                 if (k <= 0) continue;
                 int const m = std::min(k - 1 + R2, n - col0);
-                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.VTb + (size_t)t * 2 * R2 * R2, ws.W1q, n, m, k,
-                    Q + (size_t)col0 * ldq, ldq);
-                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, ws.W1q,
-                    n, m, k, Z + (size_t)col0 * ldz, ldz);
+                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.VTb + (size_t)t * 2 * R2 * R2, m, k,
+                    Q + (size_t)col0 * ldq, ldq, n);
+                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, m, k,
+                    Z + (size_t)col0 * ldz, ldz, n);
             }
             if (sq != s || C > 1) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
         }
