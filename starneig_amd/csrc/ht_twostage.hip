@@ -310,32 +310,31 @@ __device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, 
 }
 
 // X(p:p1, cb:n) <- (I - tau v v^T) X for X = A (z = 0, cb = c0 + 1) and X = B (z = 1, cb = p): 16 lanes per
-// column, four rows each (DPP sums); blockIdx.x: chunk of LEFT_CHUNK columns, four per 16-lane group, all in
-// flight together; blockIdx.y: step
-constexpr int LEFT_CHUNK = 64;
-__global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__restrict__ A, int lda,
+// column, four rows each (DPP sums); a workgroup of 1024 threads takes a chunk of LEFT_CHUNK columns, four per 16-lane
+// group, all in flight together
+constexpr int LEFT_CHUNK = 128;
+__device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chunk, int z, double *__restrict__ A, int lda,
     double *__restrict__ B, int ldb, double const *__restrict__ HV, double const *__restrict__ HT)
 {
-    int const k = blockIdx.y;
     int p, p1, c0, ridx;
     if (!step_of(w, k, p, p1, c0, ridx)) return;
     double const tau = HT[ridx];
     if (tau == 0.0) return;
-    bool const isB = blockIdx.z == 1;
+    bool const isB = z == 1;
     double *X = isB ? B : A;
     int const ld = isB ? ldb : lda, cb = isB ? p : c0 + 1, len = p1 - p;
-    int const cbeg = cb + blockIdx.x * LEFT_CHUNK;
+    int const cbeg = cb + chunk * LEFT_CHUNK;
     if (cbeg >= w.n) return;
-    int const tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;            // 16 column groups per block
+    int const tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;            // 64 column groups per block
     int const r0 = 4 * l16;
     double v[4];
     #pragma unroll
     for (int q = 0; q < 4; q++) v[q] = (r0 + q < len) ? HV[(size_t)ridx * R2 + r0 + q] : 0.0;
-    constexpr int NC = LEFT_CHUNK / 16;
+    constexpr int NC = LEFT_CHUNK / 64;
     double y[NC][4], d[NC];
     #pragma unroll
     for (int u = 0; u < NC; u++) {
-        int const c = cbeg + grp + 16 * u;
+        int const c = cbeg + grp + 64 * u;
         double const *x = X + (size_t)c * ld + p + r0;
         d[u] = 0.0;
         #pragma unroll
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256) void ht2_apply_left_kernel(Wave2 w, double *__
     for (int u = 0; u < NC; u++) d[u] = row16_sum(d[u]) * tau;
     #pragma unroll
     for (int u = 0; u < NC; u++) {
-        int const c = cbeg + grp + 16 * u;
+        int const c = cbeg + grp + 64 * u;
         double *x = X + (size_t)c * ld + p + r0;
         #pragma unroll
         for (int q = 0; q < 4; q++) if (c < w.n && r0 + q < len) x[q] = y[u][q] - d[u] * v[q];
@@ -391,25 +390,22 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
     if (kind == 1 && part == 0 && live && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
 }
 
-// Both reflectors of every step of the wavefront, one workgroup per step.  Wave 0: the left reflector H = I - th v
-// v^T from A's overhanging column (v, th -> the step's entry of HV, HT; the column is reduced in place).  All: the block
-// Bb = B(p:p1, p:p1) as it stands BEFORE H (the wide left application of this wavefront follows this kernel and
-// does not have to precede it), M = H Bb formed in LDS, then the opposite reflector: x orthogonal to rows 1 ..
-// len-1 of M (QR of those rows, transposed; x = the last column of the full Q) and G = I - tz w w^T with
-// G e_1 = +-x (w, tz -> GV, GT).  Bb is a full block (the bulge of B travels with the sweep; a step
-// restores its first column only), so there is no triangular short cut to x.
-__global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT)
+// The reflectors of a wavefront in two kernels.  (1) ht2_genh_kernel, one small workgroup per step: the left reflector
+// H = I - th v v^T from A's overhanging column (v, th -> the step's entry of HV, HT; the column is reduced in place)
+// and a copy of the step's block Bb = B(p:p1, p:p1) as it stands BEFORE H.  (2) ht2_geng_left_kernel: its first
+// `count` workgroups form the opposite reflectors from those copies -- M = H Bb in LDS, x orthogonal to rows 1 ..
+// len-1 of M (QR of those rows, transposed; x = the last column of the full Q), G = I - tz w w^T with G e_1 = +-x
+// (w, tz -> GV, GT) --, 75 us of latency on 60 of 256 CUs, WHILE the rest of its workgroups apply the left reflectors
+// to the rows of A and B, the HBM-bound part: a wavefront is 5 us + max(75 us, left) + right instead of 75 us + left +
+// right.  Bb is a full block (the bulge of B travels with the sweep; a step restores its first column only), so
+// there is no triangular short cut to x.
+__global__ __launch_bounds__(256) void ht2_genh_kernel(Wave2 w, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
+    double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ Bcopy)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int LQ = R2 + 1;
-    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
-    __shared__ double s_th;
     int const k = blockIdx.x, tid = threadIdx.x;
     int p, p1, c0, ridx;
     if (!step_of(w, k, p, p1, c0, ridx)) return;
-    HV += (size_t)ridx * R2; GV += (size_t)ridx * R2; HT += ridx; GT += ridx;
-    int const len = p1 - p, kq = len - 1;
+    int const len = p1 - p;
     if (tid < 64) {
         int const lane = tid;
         double *col = A + (size_t)c0 * lda + p;
@@ -418,14 +414,41 @@ __global__ __launch_bounds__(QT) void ht2_gen_kernel(Wave2 w, double *__restrict
         double const alpha = __shfl(x, 0);
         double t = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) { beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
-        double const v = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
-        HV[lane] = v; s_v[lane] = v;
-        if (lane == 0) { HT[0] = t; s_th = t; }
+        HV[(size_t)ridx * R2 + lane] = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
+        if (lane == 0) HT[ridx] = t;
         if (lane < len) col[lane] = lane == 0 ? beta : 0.0;
-    } else {
-        for (int idx = tid - 64; idx < len * len; idx += QT - 64) {
+    }
+    double *Bc = Bcopy + (size_t)k * R2 * R2;
+    for (int idx = tid; idx < len * len; idx += 256) {
+        int const i = idx % len, j = idx / len;
+        Bc[j * R2 + i] = B[(size_t)(p + j) * ldb + p + i];
+    }
+}
+
+__global__ __launch_bounds__(QT, 8) void ht2_geng_left_kernel(Wave2 w, int nchunk, double *__restrict__ A, int lda, double *__restrict__ B, int ldb,
+    double const *__restrict__ HV, double const *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT,
+    double const *__restrict__ Bcopy)
+{
+    if ((int)blockIdx.x >= w.count) {
+        int const idx = blockIdx.x - w.count, chunk = idx % nchunk, rest = idx / nchunk;
+        apply_left_chunk(w, rest % w.count, chunk, rest / w.count, A, lda, B, ldb, HV, HT);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int LQ = R2 + 1;
+    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
+    int const k = blockIdx.x, tid = threadIdx.x;
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    GV += (size_t)ridx * R2; GT += ridx;
+    int const len = p1 - p, kq = len - 1;
+    double const s_th = HT[ridx];
+    if (tid < R2) s_v[tid] = HV[(size_t)ridx * R2 + tid];
+    {
+        double const *Bc = Bcopy + (size_t)k * R2 * R2;
+        for (int idx = tid; idx < len * len; idx += QT) {
             int const i = idx % len, j = idx / len;
-            Bs[j * LQ + i] = B[(size_t)(p + j) * ldb + p + i];
+            Bs[j * LQ + i] = Bc[j * R2 + i];
         }
     }
     __syncthreads();
@@ -660,6 +683,8 @@ struct Ht2Workspace {
     double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
     double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
+    double *Bcopy = nullptr;                        // stage 2: the steps' blocks of B as they stand before the left reflectors
+    int maxcount = 0;
     bool attr = false;
     hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
     hipStream_t cstream[3] = {};                    // stage 2: the chains of sweeps beside the caller's stream
@@ -671,7 +696,7 @@ struct Ht2Workspace {
         if (!attr) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_geng_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_LEFT_LDS));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_right_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_RIGHT_LDS));
@@ -709,10 +734,12 @@ struct Ht2Workspace {
         size_t const refl = (size_t)ht2_nslot(n) * GS * ht2_tstride(n);
         alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
         alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(VTb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2);
+        maxcount = n / (LAG * R2 - 1) + 4;
+        alloc(Bcopy, (size_t)maxcount * R2 * R2);
     }
     void release()
     {
-        double **all[] = {&V, &VT, &HV, &HT, &GV, &GT, &Vb, &VTb};
+        double **all[] = {&V, &VT, &HV, &HT, &GV, &GT, &Vb, &VTb, &Bcopy};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
@@ -877,9 +904,12 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             bool const moved = prev_cnt[c] == 0 || (c < C - 1 && b1 > prev_top[c]);
             if (moved && prev_wave_last && C > 1) SN_HIP_CHECK(hipStreamWaitEvent(st, prev_wave_last, 0));
             Wave2 const w{n, tau_idx, b0, cnt, tstride, nslot};
-            hipLaunchKernelGGL(ht2_gen_kernel, dim3(cnt), dim3(QT), GEN_LDS_BYTES, st, w, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT);
             if (last_ev && last_stream != st) SN_HIP_CHECK(hipStreamWaitEvent(st, last_ev, 0));
-            hipLaunchKernelGGL(ht2_apply_left_kernel, dim3(divceil(n, LEFT_CHUNK), cnt, 2), dim3(256), 0, st, w, A, lda, B, ldb, ws.HV, ws.HT);
+            if (cnt > ws.maxcount) return -1;
+            int const nchunk = divceil(n, LEFT_CHUNK);
+            hipLaunchKernelGGL(ht2_genh_kernel, dim3(cnt), dim3(256), 0, st, w, A, lda, B, ldb, ws.HV, ws.HT, ws.Bcopy);
+            hipLaunchKernelGGL(ht2_geng_left_kernel, dim3(cnt + cnt * 2 * nchunk), dim3(QT), GEN_LDS_BYTES, st, w, nchunk, A, lda, B, ldb,
+                ws.HV, ws.HT, ws.GV, ws.GT, ws.Bcopy);
             hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), cnt, 2), dim3(256), 0, st, w,
                 RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
             if (C > 1) { SN_HIP_CHECK(hipEventRecord(ws.lr[c], st)); last_ev = ws.lr[c]; }
