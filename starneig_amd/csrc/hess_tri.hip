@@ -921,8 +921,8 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht_chain_kernel<HG, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_DOUBLES(HG) * 8));
         attr_set = true;
     }
-    // The two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps: a developer switch
-    // (SN_HT_TWOSTAGE=1) -- DESIGN.md section 4d has the measurements and why the rotation path stays the default
+    // From n = 1500 on the two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps (twice
+    // as fast at n = 8000; SN_HT_TWOSTAGE=0 / 1 forces either) -- DESIGN.md section 4d has the measurements
     int const two_stage = n >= 3 && (tuning().ht_two_stage > 0 || (tuning().ht_two_stage < 0 && n >= tuning().ht2_min_n));
     if (two_stage) {
         static hipEvent_t between = nullptr;

@@ -1,19 +1,21 @@
 // Two-stage reduction of a pencil (A, B), B upper triangular, to Hessenberg-triangular form (the step the
-// reference delegates to LAPACK dgghd3, wrappers/lapack.c:143-163) -- the alternative to the rotation path of
-// hess_tri.hip whose n^2/2 dependent column rotations bound it.
+// reference delegates to LAPACK dgghd3, wrappers/lapack.c:143-163) -- from n = 1500 on the product path instead of
+// the rotations of hess_tri.hip, whose n^2/2 dependent column rotations bound them.
 //
 //   Stage 1 (Dackland & Kagstrom; Kagstrom, Kressner, Quintana-Orti, Quintana-Orti 2008): block column by block
 //   column (r = 64 wide), bottom up, QR of the (2r x r) blocks of the panel -- reflectors from the left on A, B, Q;
 //   the diagonal block of B they fill is restored by r reflectors from the right (RQ of its bottom r rows) on
 //   B, A, Z; one RQ of the full r x r block that remains at the top of the block column.  A ends with r
-//   sub-diagonals.  Compact-WY factors, every application three fp64 MFMA GEMMs.
+//   sub-diagonals.  Compact-WY factors (V and V T^T from the factorisation kernels), one kernel per application.
 //   Stage 2: a Householder bulge chase.  Sweep j, position t: the left reflector of length r that reduces the
-//   overhanging column (rows p .. p + r - 1, p = j + 1 + t r), applied to the rows of A, B and to Q; the
-//   "opposite" reflector from the right whose first column is orthogonal to rows 2 .. r of the r x r block of B
-//   (QR of those rows in LDS: no solve with B, singular B included), applied to the columns of B, A and to Z.
-//   Sweep j + 1 may run position t once sweep j has left position t + 2: wavefronts of ~n / (3 r) independent
-//   steps, four launches each (build / apply left, build / apply right).
-// scratch/ht2_proto.py is the numpy statement of the same algorithm (tests/test_ht_twostage_prototype.py).
+//   overhanging column (rows p .. p + r - 1, p = j + 1 + t r), applied to the rows of A, B; the "opposite"
+//   reflector from the right whose first column is orthogonal to rows 2 .. r of the r x r block of B (QR of those
+//   rows in LDS: no solve with B, singular B included), applied to the columns of B, A.  Sweep j + 1 runs position
+//   t while sweep j runs position t + 2: wavefronts of ~n / (2 r) independent steps, three launches each (left
+//   reflectors; opposite reflectors under the left application; right application).  Q and Z take the reflectors
+//   of 64 sweeps at a time as compact-WY blocks on a second stream.
+// scratch/ht2_proto.py and scratch/ht2_lag.py are the numpy statements of the algorithm and of this order
+// (tests/test_ht_twostage_prototype.py).
 #include "common.h"
 #include "tuning.h"
 #include <algorithm>
