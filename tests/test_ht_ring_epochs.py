@@ -1,0 +1,80 @@
+"""CPU: model of the slot rings of stage 1 of the two-stage Hessenberg-triangular reduction (csrc/ht_twostage.hip,
+`epoch_record` / `epoch_wait`).  A producer stream fills slot L mod RING in step L and records `ready`; consumer streams
+wait for `ready`, read the slot, and tell the producer that slots are free again only once per EPOCH = RING / 2 steps,
+through two alternating events (the host is the bottleneck of that loop: every runtime call counts).  HIP semantics:
+a wait refers to the most recent record of the event that was ENQUEUED before it.  Under every interleaving of the
+streams a consumer must find in a slot what its step put there."""
+import random
+
+import pytest
+
+RING, EPOCH = 8, 4
+
+
+def enqueue(nsteps, consumers):
+    """the host loop: per-stream op lists; ops are ("wait", record_id | None), ("write", L), ("read", L), ("record", id)"""
+    streams = {"P": []}
+    for c in consumers:
+        streams[c] = []
+    last = {}                       # event name -> id of its most recent enqueued record
+    next_id = [0]
+
+    def record(stream, ev):
+        next_id[0] += 1
+        last[ev] = next_id[0]
+        streams[stream].append(("record", next_id[0]))
+
+    def wait(stream, ev):
+        streams[stream].append(("wait", last.get(ev)))
+
+    for L in range(nsteps):
+        sl = L % RING
+        if L >= RING and L % EPOCH == 0:                     # epoch_wait(used_*, L, producer)
+            for c in consumers:
+                wait("P", (c, (L // EPOCH) % 2))
+        streams["P"].append(("write", L))
+        record("P", ("ready", sl))
+        for c in consumers:
+            wait(c, ("ready", sl))
+            streams[c].append(("read", L))
+            if L % EPOCH == EPOCH - 1:                       # epoch_record(used_*, L, consumer)
+                record(c, (c, (L // EPOCH) % 2))
+    return streams
+
+
+def run(streams, rng):
+    done, slots, pos = set(), {}, {k: 0 for k in streams}
+    while any(pos[k] < len(v) for k, v in streams.items()):
+        ready = []
+        for k, ops in streams.items():
+            if pos[k] < len(ops):
+                op, arg = ops[pos[k]]
+                if op != "wait" or arg is None or arg in done:
+                    ready.append(k)
+        assert ready, "deadlock"
+        k = rng.choice(ready)
+        op, arg = streams[k][pos[k]]
+        if op == "write":
+            slots[arg % RING] = arg
+        elif op == "read":
+            assert slots.get(arg % RING) == arg, (k, arg, slots.get(arg % RING))
+        elif op == "record":
+            done.add(arg)
+        pos[k] += 1
+
+
+@pytest.mark.parametrize("consumers", [("s",), ("s", "sq")])
+def test_ring_slots_are_never_overwritten_before_they_are_read(consumers):
+    rng = random.Random(5)
+    for trial in range(300):
+        run(enqueue(rng.choice([1, 7, 8, 9, 23, 64]), consumers), rng)
+
+
+def test_the_model_notices_a_missing_wait():
+    """the same loop with the producer's waits one epoch late must fail under some interleaving"""
+    streams = enqueue(40, ("s",))
+    streams["P"] = [op for op in streams["P"] if op[0] != "wait"]
+    rng = random.Random(1)
+    with pytest.raises(AssertionError):
+        for trial in range(300):
+            run({k: list(v) for k, v in streams.items()}, rng)
