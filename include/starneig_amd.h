@@ -41,9 +41,10 @@ starneig_error_t starneig_amd_hessenberg_device(
  * (torch.distributed over RCCL in starneig_amd/distributed.py).  With BOTH callbacks NULL the
  * collectives are issued to RCCL directly on `stream` (no host round trip per panel column), through
  * the communicator of starneig_amd_rccl_init.
- * stats (may be NULL) is double[8]: [0] total ms, [1] algorithmic bytes this rank's gemv launches
- * streamed, [2] executed GEMM flops, [5] gemv launches.  With stats[7] = k >= 1 ON ENTRY the array is
- * double[32] and every k-th gemv launch (with the all-reduce behind it) and every per-panel collective is
+ * stats (may be NULL) is ALWAYS double[32], zero-initialised by the caller (it is read on entry): out [0] total
+ * ms, [1] algorithmic bytes this rank's gemv launches streamed, [2] executed GEMM flops, [5] gemv launches.
+ * In: stats[7] = k, an integer in [1, 2^20] (anything else -- NaN, a fraction, out of range -- counts as 0 =
+ * off): every k-th gemv launch (with the all-reduce behind it) and every per-panel collective is
  * timed with HIP events on `stream` (scaling report): [8] ms, [9] bytes, [10] count of the
  * sampled launches; [11] per-column all-reduces issued; [12 + 3i .. 14 + 3i] ms, payload bytes, timed calls
  * of collective kind i = 0 all-reduce of y (sampled columns), 1 panel broadcast, 2 all-reduce of W, 3 assembly

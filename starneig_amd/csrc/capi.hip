@@ -832,7 +832,10 @@ SN_API starneig_error_t starneig_amd_hessenberg_device(
     if (panel_width <= 0) panel_width = default_panel_width(n);
     if (panel_width < 8) return STARNEIG_INVALID_CONFIGURATION;
     sn::HessenbergTimings tm;
-    if (stats) tm.sample_every = (int)stats[7];
+    if (stats) {   // in: [7] = k, an integer in [1, 2^20]; anything else is "off"
+        double const k_in = stats[7];
+        tm.sample_every = (k_in >= 1.0 && k_in <= 1048576.0 && k_in == (double)(long)k_in) ? (int)k_in : 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     int rc = sn::hessenberg_device(s, n, begin, end, panel_width, dA, ldA, dQ, ldQ,
         stats ? &tm : nullptr);
@@ -899,10 +902,12 @@ SN_API starneig_error_t starneig_amd_hessenberg_sharded_device(
     sn::HessComm comm{rank, world, native ? native_allreduce : allreduce_sum, native ? native_broadcast : broadcast,
                       native ? (void *)&nc : ctx};
     sn::HessenbergTimings tm;
-    // stats[7] > 0 on entry: `stats` holds 32 doubles and every stats[7]-th gemv launch (with its all-reduce)
-    // and every per-panel collective is event-timed (include/starneig_amd.h)
-    bool const detailed = stats && stats[7] >= 1.0;
-    if (detailed) tm.sample_every = (int)stats[7];
+    // `stats` holds 32 zero-initialised doubles; stats[7] = k on entry: every k-th gemv launch (with its
+    // all-reduce) and every per-panel collective is event-timed (include/starneig_amd.h).  Only an integer in
+    // [1, 2^20] switches the detailed report on -- an uninitialised array must not
+    double const k_in = stats ? stats[7] : 0.0;
+    bool const detailed = stats && k_in >= 1.0 && k_in <= 1048576.0 && k_in == (double)(long)k_in;
+    if (detailed) tm.sample_every = (int)k_in;
     int rc = sn::hessenberg_sharded_device(s, n, panel_width, dA, ldA, dQ, ldQ, dY, dP, dW,
         w_capacity, comm, stats ? &tm : nullptr);
     SN_HIP_CHECK(hipStreamSynchronize(s));

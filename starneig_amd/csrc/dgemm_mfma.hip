@@ -23,6 +23,7 @@
 #include "dgemm_tile.h"
 #include "tuning.h"
 #include <algorithm>
+#include <vector>
 
 namespace sn {
 
@@ -56,30 +57,34 @@ void dgemm_kernel(int m, int n, int k, double alpha,
     int bm, bn;
     if (!SPLIT || (int)blockIdx.x < whole) {
         tile_of(blockIdx.x, total, tiles_m, bm, bn);
-        gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn, false, separate_sum != 0);
+        gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, bm, bn, separate_sum != 0);
         return;
     }
     if (SPLIT) {
         int const q = blockIdx.x - whole, piece = q % pieces;
         tile_of(whole + q / pieces, total, tiles_m, bm, bn);
         if (pieces == 2)
-            gemm_tile<BM / 2, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + piece, bn, false, separate_sum != 0);
+            gemm_tile<BM / 2, BN, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + piece, bn, separate_sum != 0);
         else
-            gemm_tile<BM / 2, BN / 2, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + (piece & 1), 2 * bn + (piece >> 1), false, separate_sum != 0);
+            gemm_tile<BM / 2, BN / 2, KT, TA, TB, FLUSH>(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 2 * bm + (piece & 1), 2 * bn + (piece >> 1), separate_sum != 0);
     }
 }
 
 // Split-K form for outputs with few tiles and a long inner dimension (the inner-product shaped
 // GEMMs of the Hessenberg path: W = A^T (V T), W = X (V T), S = Y^T (V T) -- skinny n = panel
-// width, k = trailing rows): blockIdx.y selects a slice of k, the slices are summed into C
-// (zeroed by the caller) with fp64 atomics.  Besides filling the chip this shortens the
-// sequential accumulation chains from k to k / slices terms.
+// width, k = trailing rows): blockIdx.y selects a slice of k; slice y writes ITS product into plane y of a
+// scratch buffer (m x n, leading dimension m, plain stores) and dgemm_splitk_sum_kernel adds the planes up in
+// slice order.  Besides filling the chip this shortens the sequential accumulation chains from k to
+// k / slices terms.  (Rounds 1-5 summed the slices into C with fp64 atomics: the order of the partial sums, and
+// with it the last bits of every Hessenberg reduction, varied from run to run and from replica to replica.)
 template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH>
 __global__ __launch_bounds__(256, 2)
 void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double *__restrict__ C, int ldc, int tiles_m)
+    double *__restrict__ planes, int tiles_m)
 {
+    double *C = planes + (size_t)blockIdx.y * m * n;
+    int const ldc = m;
     int const k0 = blockIdx.y * kchunk, kl = min(kchunk, k - k0);
     if (kl <= 0) return;
     // Tile order (speed only): the few column tiles of ONE row panel go to the same XCD back to back
@@ -91,7 +96,55 @@ void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     if (bm >= tiles_m) return;
     double const *Ak = TA ? A + k0 : A + (size_t)k0 * lda;
     double const *Bk = TB ? B + (size_t)k0 * ldb : B + k0;
-    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc, bm, bn, true);
+    gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc, bm, bn);
+}
+
+// C(r, c) = plane_0(r, c) + plane_1(r, c) + ... in slice order: one thread per row pair, all planes in flight
+__global__ __launch_bounds__(256)
+void dgemm_splitk_sum_kernel(int m, int n, int slices, double const *__restrict__ planes, double *__restrict__ C, int ldc)
+{
+    int const r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    size_t const plane = (size_t)m * n;
+    for (int c = blockIdx.y; c < n; c += gridDim.y) {
+        double const *p = planes + (size_t)c * m + r;
+        double s = p[0];
+        int y = 1;
+        for (; y + 4 <= slices; y += 4) {
+            double const a = p[(size_t)y * plane], b = p[(size_t)(y + 1) * plane], d = p[(size_t)(y + 2) * plane], e = p[(size_t)(y + 3) * plane];
+            s += a; s += b; s += d; s += e;
+        }
+        for (; y < slices; y++) s += p[(size_t)y * plane];
+        C[(size_t)c * ldc + r] = s;
+    }
+}
+
+// scratch planes of the split-K products: one buffer per (host thread, stream) -- the critical stream and the
+// side stream of a reduction run their products concurrently
+struct SplitkSlot { hipStream_t s; double *p; size_t cap; };
+static thread_local std::vector<SplitkSlot> g_splitk_slots;
+void dgemm_release_workspace()
+{
+    for (SplitkSlot &q : g_splitk_slots) if (q.p) SN_HIP_CHECK(hipFree(q.p));
+    g_splitk_slots.clear();
+}
+static double *splitk_planes(hipStream_t s, size_t doubles)
+{
+    typedef SplitkSlot Slot;
+    std::vector<Slot> &slots = g_splitk_slots;
+    for (Slot &q : slots)
+        if (q.s == s) {
+            if (q.cap < doubles) {
+                SN_HIP_CHECK(hipStreamSynchronize(s));
+                SN_HIP_CHECK(hipFree(q.p));
+                SN_HIP_CHECK(hipMalloc((void **)&q.p, doubles * sizeof(double))); q.cap = doubles;
+            }
+            return q.p;
+        }
+    Slot q{s, nullptr, doubles};
+    SN_HIP_CHECK(hipMalloc((void **)&q.p, doubles * sizeof(double)));
+    slots.push_back(q);
+    return q.p;
 }
 
 // Batched form: blockIdx.y selects a problem descriptor (alpha = 1, beta = 0).  Used for the
@@ -177,9 +230,11 @@ static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double
     }
     int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
     int const tiles_m = divceil(m, BM), tiles = 8 * divceil(tiles_m, 8) * divceil(n, BN);   // (rounded up: see the kernel's tile order)
-    SN_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(double), 0, (size_t)m * sizeof(double), n, s));
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, divceil(k, kchunk)), dim3(256), Cfg::LDS_BYTES, s,
-        m, n, k, kchunk, alpha, A, lda, B, ldb, C, ldc, tiles_m);
+    int const nsl = divceil(k, kchunk);
+    double *planes = splitk_planes(s, (size_t)nsl * m * n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, nsl), dim3(256), Cfg::LDS_BYTES, s,
+        m, n, k, kchunk, alpha, A, lda, B, ldb, planes, tiles_m);
+    hipLaunchKernelGGL(dgemm_splitk_sum_kernel, dim3(divceil(m, 256), std::min(n, 256)), dim3(256), 0, s, m, n, nsl, planes, C, ldc);
 }
 
 template <bool TA, bool TB>
@@ -190,8 +245,8 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
     // (only inner-product shapes, min(m,n) << k: the square window products of the Schur path must
     // stay deterministic -- replicas of one reduction on several GPUs rely on it)
     if (beta == 0.0 && k >= 2048 && (long)std::min(m, n) * 4 <= k) {
-        // Few output tiles, long k: split k over the chip (fp64 atomics; the order of the partial
-        // sums varies from run to run in the last bits, like the reference's STARPU_COMMUTE sums).
+        // Few output tiles, long k: split k over the chip (the slices' products are added in slice order:
+        // the same bits in every run, unlike the reference's STARPU_COMMUTE sums).
         // Target: ~6 work items per workgroup slot (256 CUs x 2), slices of >= 512.
         long const t128 = (long)divceil(m, 128) * divceil(n, 64);
         long const t64 = (long)divceil(m, 64) * divceil(n, 64);

@@ -34,8 +34,7 @@ template <int BM, int BN, int KT, bool TA, bool TB, int FLUSH = 0>
 __device__ __forceinline__
 void gemm_tile(int m, int n, int k, double alpha,
     double const *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double beta, double *__restrict__ C, int ldc, int bm, int bn, bool atomic = false,
-    bool separate_sum = false)
+    double beta, double *__restrict__ C, int ldc, int bm, int bn, bool separate_sum = false)
 {
     using Cfg = GemmCfg<BM, BN, KT, TA, TB>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -52,7 +51,7 @@ void gemm_tile(int m, int n, int k, double alpha,
     // accumulators START as the old C tile and the column operand carries the sign, so the tile
     // is read while the first operand tiles are in flight and the epilogue is stores only --
     // instead of a dependent load / fma / store tail after the last MFMA.
-    bool const accinit = !atomic && !separate_sum && beta == 1.0 && (alpha == 1.0 || alpha == -1.0);
+    bool const accinit = !separate_sum && beta == 1.0 && (alpha == 1.0 || alpha == -1.0);
     double const opscale = accinit ? alpha : 1.0;
     // interior tiles: straight 16-byte loads, no per-element bounds tests
     bool const tile_full = (r0 + BM <= m) && (c0 + BN <= n);
@@ -250,7 +249,7 @@ void gemm_tile(int m, int n, int k, double alpha,
             }
         return;
     }
-    if (beta != 0.0 && !atomic) {
+    if (beta != 0.0) {
         // C <- alpha * sum + beta * C: the old values of column group ci + 1 are requested BEFORE group ci
         // is stored (the groups are different columns), so the epilogue costs one memory latency, not
         // one per group; the loads are unconditional from clamped addresses (a predicated load makes
@@ -294,8 +293,7 @@ void gemm_tile(int m, int n, int k, double alpha,
                 int c = c0 + wn * Cfg::WN + ci * 16 + l4 + 4 * reg;
                 if (r < m && c < n) {
                     double v = alpha * acc[ci][ri][reg];
-                    if (atomic) atomicAdd(&C[(size_t)c * ldc + r], v);      // split-K slice
-                    else C[(size_t)c * ldc + r] = v;
+                    C[(size_t)c * ldc + r] = v;
                 }
             }
         }

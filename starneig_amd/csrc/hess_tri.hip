@@ -885,19 +885,22 @@ void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, doub
 } // namespace
 
 void ht_two_stage_release_workspace();
+bool ht_two_stage_fits(int n);
 int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda, double *B, int ldb, double *Q, int ldq,
     double *Z, int ldz, hipEvent_t between);
 void hessenberg_triangular_release_workspace() { g_ht.release_buffers(); ht_two_stage_release_workspace(); }
 
 // (dA, dB) general -> (H, T) upper Hessenberg / upper triangular with dQ <- dQ*U1, dZ <- dZ*U2
-// (dQ, dZ may be NULL).  stats (may be NULL): [0] total ms, [1] QR step ms, [2] rotation step ms,
-// [3] executed GEMM flops, [4] rotations.
+// (dQ, dZ may be NULL).  stats (may be NULL) is double[8]: [0] total ms, [1] QR step ms, [2] ms of the reduction
+// proper (rotation sweeps, or both stages of the two-stage path), [3] executed GEMM flops, [4] rotations (0 on the
+// two-stage path), [5] 1 if the two-stage path ran, else 0, [6] its stage 1 ms (else 0), [7] unused.
 int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA, double *dB, int ldB,
     double *dQ, int ldQ, double *dZ, int ldZ, double *stats)
 {
     HtWorkspace &ws = g_ht;
     ws.ensure(n);
     double flops = 0.0, rotations = 0.0;
+    if (stats) { stats[5] = 0.0; stats[6] = 0.0; stats[7] = 0.0; }
     // the dependent path runs on a stream of the highest priority: its small kernels (one workgroup
     // with 100 KB of LDS) must not queue behind the thousands of workgroups of the streaming passes
     hipStream_t const s = ws.main;
@@ -923,7 +926,8 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
     }
     // From n = 1500 on the two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps (twice
     // as fast at n = 8000; SN_HT_TWOSTAGE=0 / 1 forces either) -- DESIGN.md section 4d has the measurements
-    int const two_stage = n >= 3 && (tuning().ht_two_stage > 0 || (tuning().ht_two_stage < 0 && n >= tuning().ht2_min_n));
+    int const two_stage = ht_two_stage_fits(n) && (tuning().ht_two_stage > 0 || (tuning().ht_two_stage < 0 && n >= tuning().ht2_min_n));
+    int two_stage_rc = 0;
     if (two_stage) {
         static hipEvent_t between = nullptr;
         if (!between) SN_HIP_CHECK(hipEventCreate(&between));
@@ -933,8 +937,10 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         // the Householder kernels of this path take plain sums of squares: A, like B, to max |a| in [1, 2)
         hipLaunchKernelGGL(ht_absmax_kernel, dim3(std::min(16, divceil(n, 256)), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2);
         hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2, 1);
-        int const rc2 = ht_two_stage_device(s, ws.qstream, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
-        if (rc2 != 0) return STARNEIG_GENERIC_ERROR;
+        // (it refuses a problem before its first launch, never in the middle: on an error the scaling is still undone
+        // and the streams are joined below before the call returns)
+        two_stage_rc = ht_two_stage_device(s, ws.qstream, n, dA, ldA, dB, ldB, dQ, ldQ, dZ, ldZ, between);
+        if (two_stage_rc != 0) SN_HIP_CHECK(hipEventRecord(between, s));
         hipLaunchKernelGGL(ht_scale_kernel, dim3(divceil(n, 256), n), dim3(256), 0, s, n, dA, ldA, ws.amax + 2, -1);
         if (stats) { stats[5] = 1.0; }
         SN_HIP_CHECK(hipEventRecord(ws.e_side, s));
@@ -1017,6 +1023,11 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         SN_HIP_CHECK(hipEventElapsedTime(&t01, ws.ev[0], ws.ev[1]));
         SN_HIP_CHECK(hipEventElapsedTime(&t12, ws.ev[1], ws.ev[2]));
         stats[0] = t01 + t12; stats[1] = t01; stats[2] = t12; stats[3] = flops; stats[4] = rotations;
+    }
+    if (two_stage_rc != 0) {
+        fprintf(stderr, "[starneig-amd] Hessenberg-triangular reduction: the two-stage path refused n = %d (%d); "
+            "A and B are not reduced.\n", n, two_stage_rc);
+        return STARNEIG_GENERIC_ERROR;
     }
     if (chain_err) {
         fprintf(stderr, "[starneig-amd] Hessenberg-triangular reduction: a wait inside the chain kernel timed out; "

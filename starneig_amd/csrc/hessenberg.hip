@@ -18,8 +18,13 @@
 //             of VT = V*T (VT(:,j) = tau (v - VT w_v), which is V t_j + tau v with
 //             t_j = -tau T w_v of cpu.c:277-284), in the gemv's shadow.
 // T itself is never formed: every consumer needs V*T only.  Cross-workgroup sums
-// (w, w_v, the norm) are fp64 atomics into 8 slots that the consumers add up; the
-// reflector scalars (LAPACK dlarfg, cpu.c:137-141) are recomputed by each consumer.
+// (w, w_v, the norm) are ORDERED: every workgroup stores its partial vector, the workgroups
+// b = s, s + 16, ... share slot s, and the one that draws the slot's last ticket adds the slot's
+// partials up in workgroup order (slot_fold below); the consumers add the 16 slot sums in slot
+// order.  Two reductions of one matrix give the same bits, and so do the replicas of a sharded
+// reduction (rounds 1-5 used fp64 atomics into 8 slots: the reference's STARPU_COMMUTE
+// accumulations, hessenberg/tasks.c:374,515,622, and like them different in the last bits from
+// run to run).  The reflector scalars (LAPACK dlarfg, cpu.c:137-141) are recomputed by each consumer.
 // All panel matrices (P,V,VT,Y) are indexed by GLOBAL row so that the 16-byte row
 // pairs of the gemv stay aligned for every panel offset.
 #include "common.h"
@@ -66,14 +71,16 @@ constexpr int RBS = 32, NGS = 8;  // rows / column groups of a shadow block insi
                                   // ~5 streaming workgroups per CU they must all be resident at once (8 per CU)
 constexpr int GEMV_ROWS = 512;   // rows per workgroup of the big gemv (4 waves x 64 lanes x 2)
 constexpr int MAX_SPLIT = 64;
-constexpr int NSLOT = 8;         // atomic accumulator slots (spreads same-address contention)
+constexpr int NSLOT = 16;        // slots of the ordered cross-workgroup sums (workgroup b belongs to slot b % NSLOT)
 constexpr int MAXJ = 512;        // panel width limit of the column kernels
 
-// accumulator layout (doubles): wsum[2][NSLOT][MAXJ], wvsum[2][NSLOT][MAXJ], nrm[2][NSLOT]
+// slot sums (doubles): wsum[NSLOT][MAXJ], wvsum[NSLOT][MAXJ], nrm[NSLOT]; a slot without a workgroup keeps the
+// zero of the panel's memset.  Every value is OVERWRITTEN by its slot's last arriver, never accumulated: no
+// zeroing between columns, no second parity.
 constexpr int ACC_WSUM = 0;
-constexpr int ACC_WVSUM = 2 * NSLOT * MAXJ;
-constexpr int ACC_NRM = 4 * NSLOT * MAXJ;
-constexpr int ACC_TOTAL = ACC_NRM + 2 * NSLOT;
+constexpr int ACC_WVSUM = NSLOT * MAXJ;
+constexpr int ACC_NRM = 2 * NSLOT * MAXJ;
+constexpr int ACC_TOTAL = ACC_NRM + NSLOT;
 
 __device__ __forceinline__ double slot_sum(double const *__restrict__ base, int l)
 {
@@ -93,11 +100,11 @@ __device__ __forceinline__ void reflector_scalars(double ssq, double alpha,
     scale = 1.0 / (alpha - beta);
 }
 
-__device__ __forceinline__ double nrm_sum(double const *__restrict__ acc, int par)
+__device__ __forceinline__ double nrm_sum(double const *__restrict__ acc)
 {
     double s = 0.0;
     #pragma unroll
-    for (int k = 0; k < NSLOT; k++) s += acc[ACC_NRM + par * NSLOT + k];
+    for (int k = 0; k < NSLOT; k++) s += acc[ACC_NRM + k];
     return s;
 }
 
@@ -118,11 +125,13 @@ __device__ __forceinline__ double split_sum(double const *__restrict__ ypart, in
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
-// In-block transposed gemv: out[l] += sum_{r<RB} M[g0+r, l] * sp[r], l < ncols.
-// CT threads = 16 row lanes x CT/16 column groups; 16 lanes read 128 contiguous
-// bytes of one column, the 16-lane DPP row reduces them, one atomic per column.
+// In-block transposed gemv: out[l] = sum_{r<RB} M[g0+r, l] * sp[r], l < ncols -- this workgroup's PARTIAL of
+// the cross-workgroup sum (slot_fold adds the partials up).  CT threads = 16 row lanes x CT/16 column groups; 16
+// lanes read 128 contiguous bytes of one column, the 16-lane DPP row reduces them, one write-through store per
+// column (agent scope: the partial is read by another workgroup of this launch).
+__device__ __forceinline__ void part_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int THREADS>
-__device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M, int ldm,
+__device__ __forceinline__ void block_gemv_t_part(double const *__restrict__ M, int ldm,
     int g0, int ncols, double const *sp, double *__restrict__ out)
 {
     int const rsub = threadIdx.x & 15, csub = threadIdx.x >> 4;
@@ -146,7 +155,7 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
             #pragma unroll
             for (int it = 0; it < RB / 16; it++) acc += x[q][it] * pr[it];
             acc = row16_sum(acc);
-            if (rsub == 0) atomicAdd(out + l + q * CG, acc);
+            if (rsub == 0) part_store(out + l + q * CG, acc);
         }
     }
     for (; l < ncols; l += CG) {
@@ -155,8 +164,54 @@ __device__ __forceinline__ void block_gemv_t_atomic(double const *__restrict__ M
         #pragma unroll
         for (int it = 0; it < RB / 16; it++) acc += col[it * 16] * pr[it];
         acc = row16_sum(acc);
-        if (rsub == 0) atomicAdd(out + l, acc);
+        if (rsub == 0) part_store(out + l, acc);
     }
+}
+
+// The ordered cross-workgroup sum.  Every workgroup of the launch has stored its partial vector part[b][0:len)
+// (+ an optional scalar spart[b]) with write-through stores; here it drains them, meets at its barrier, one lane
+// RELEASES at agent scope and draws a ticket of slot b % NSLOT; the workgroup that draws the slot's LAST ticket
+// ACQUIRES and adds the slot's partials up in workgroup order b = slot, slot + NSLOT, ... -- eight loads in flight,
+// a fixed tree -- into sum[slot][0:len) (and ssum[slot]), then resets the counter.  (cdna_hip_programming.md
+// section 6, Guideline 16, counter form -- the hand-over of the sharded gemv's fold.)  The NEXT launch reads the
+// slot sums; a slot's value never depends on which workgroup came last.
+template <int THREADS>
+__device__ __forceinline__ void slot_fold(int nwg, int len, double const *__restrict__ part, double *__restrict__ sum,
+    double const *__restrict__ spart, double *__restrict__ ssum, int *__restrict__ cnt)
+{
+    __shared__ int s_last;
+    int const b = blockIdx.x, slot = b % NSLOT, members = (nwg - slot + NSLOT - 1) / NSLOT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int const last = __hip_atomic_fetch_add(cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    auto ordered = [&](double const *p, size_t stride) {
+        // member q of the slot goes to accumulator q % 8 (clamped loads, zeros beyond the last member: static
+        // register indices), the eight accumulators meet in a fixed tree
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < members; q += 8) {
+            double x[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++)
+                x[u] = __hip_atomic_load(p + (size_t)(slot + min(q + u, members - 1) * NSLOT) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            #pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += (q + u < members) ? x[u] : 0.0;
+        }
+        return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    };
+    for (int l = threadIdx.x; l < len; l += THREADS) sum[slot * MAXJ + l] = ordered(part + l, MAXJ);
+    if (spart && threadIdx.x == THREADS - 1) ssum[slot] = ordered(spart, 1);
 }
 
 // ---- device-side exchange of the sharded gemv's result (HessExchange, common.h) ------------------------------
@@ -221,6 +276,7 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ VT,
     double *__restrict__ Y, double const *__restrict__ ypart, int nsplit,
     double const *__restrict__ t12, double *__restrict__ acc, double const *__restrict__ scal,
+    double *__restrict__ part, int *__restrict__ cnt,
     HessExchange x = HessExchange{}, int seq = 0)
 {
     __shared__ double s_p[RB], s_scal[3];
@@ -228,7 +284,7 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
     int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
-    int const pivprev = R0 + j - 1, par = j & 1;
+    int const pivprev = R0 + j - 1;
     // scalars of column j-1 as published by gemv(j-1): P(piv-1, j-1) itself is overwritten
     // with beta by one block of THIS launch, so it must not be re-read here
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
@@ -258,9 +314,9 @@ void hess_colA_kernel(int R0, int E, int j, int ldp,
         s_p[r] = pval;
     }
     __syncthreads();
-    // w += VT(rows,0:j)^T p'   (rows past E contribute 0 through s_p)
-    block_gemv_t_atomic<CT>(VT, ldp, g0, j, s_p,
-        acc + ACC_WSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
+    // this workgroup's share of w = VT(rows,0:j)^T p'   (rows past E contribute 0 through s_p), then the ordered sum
+    block_gemv_t_part<CT>(VT, ldp, g0, j, s_p, part + (size_t)blockIdx.x * MAXJ);
+    slot_fold<CT>(gridDim.x, j, part, acc + ACC_WSUM, nullptr, nullptr, cnt);
 }
 
 // After the last column of a panel: finish Y(:,nb-1) and finalize P(:,nb-1).
@@ -274,7 +330,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     int const tid = threadIdx.x;
     int const r = tid & (RB - 1), h = tid >> 6;
     int const g = R0 + blockIdx.x * RB + r;
-    int const pivprev = R0 + j - 1, parp = (j - 1) & 1;
+    int const pivprev = R0 + j - 1;
     if (tid < 3) s_scal[tid] = scal[4 * (j - 1) + tid];
     if (x.world) {
         int const base = R0 & ~15, g0 = R0 + blockIdx.x * RB;
@@ -283,7 +339,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     __syncthreads();
     for (int l = tid; l < j - 1; l += CT)
         s_wv[l] = V[(size_t)l * ldp + pivprev]
-            + s_scal[0] * slot_sum(acc + ACC_WVSUM + parp * NSLOT * MAXJ, l);
+            + s_scal[0] * slot_sum(acc + ACC_WVSUM, l);
     __syncthreads();
     double yacc = 0.0;
     if (g < E)
@@ -304,16 +360,17 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
 // colC(j): p'' = p' - V(:,0:j) w ; norm^2 below the pivot ; V^T p''(piv+1:)
 __global__ __launch_bounds__(CTC)
 void hess_colC_kernel(int R0, int E, int j, int ldp,
-    double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc)
+    double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc,
+    double *__restrict__ part, double *__restrict__ npart, int *__restrict__ cnt)
 {
     __shared__ double s_w[MAXJ], s_p[RB], s_t[NGC - 1][RB];
     int const tid = threadIdx.x;
     int const r = tid & (RB - 1), h = tid >> 6;
     int const g0 = R0 + blockIdx.x * RB;
     int const g = g0 + r;
-    int const piv = R0 + j, par = j & 1;
+    int const piv = R0 + j;
     for (int l = tid; l < j; l += CTC)
-        s_w[l] = slot_sum(acc + ACC_WSUM + par * NSLOT * MAXJ, l);
+        s_w[l] = slot_sum(acc + ACC_WSUM, l);
     // requested in the same round as the slot sums (they depend on nothing computed here): this thread's
     // entry of column j and the first four entries of its row of V -- same arithmetic, one round trip less
     double const *vrow = V + g;
@@ -324,9 +381,6 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
         x0 = vrow[(size_t)(h + 0 * NGC) * ldp]; x1 = vrow[(size_t)(h + 1 * NGC) * ldp];
         x2 = vrow[(size_t)(h + 2 * NGC) * ldp]; x3 = vrow[(size_t)(h + 3 * NGC) * ldp];
     }
-    if (blockIdx.x == 0)      // wsum of the other parity: read by colC(j-1), re-used by colA(j+1)
-        for (int l = tid; l < NSLOT * MAXJ; l += CTC)
-            acc[ACC_WSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
     __syncthreads();
     double a = 0.0;
     if (g < E) {
@@ -356,20 +410,18 @@ void hess_colC_kernel(int R0, int E, int j, int ldp,
         }
         s_p[r] = below;
         double ss = wave_sum(below * below);
-        if (tid == 0)
-            atomicAdd(acc + ACC_NRM + par * NSLOT + (blockIdx.x & (NSLOT - 1)), ss);
+        if (tid == 0) part_store(npart + blockIdx.x, ss);
     }
     __syncthreads();
-    block_gemv_t_atomic<CTC>(V, ldp, g0, j, s_p,
-        acc + ACC_WVSUM + (par * NSLOT + (blockIdx.x & (NSLOT - 1))) * MAXJ);
+    block_gemv_t_part<CTC>(V, ldp, g0, j, s_p, part + (size_t)blockIdx.x * MAXJ);
+    slot_fold<CTC>(gridDim.x, j, part, acc + ACC_WVSUM, npart, acc + ACC_NRM, cnt);
 }
 
 // The big gemv: ypart[split][g] = sum_{c in split} A[g, c] * v[c],  g in [R0,E),
 // c in [piv,E), v[piv] = 1, v[c] = scale * p''[c].
 // One launch, 1-D grid:
-//   blocks [0, nshadow)  : the "shadow" blocks (64 rows each) -- V(:,j) = v and
-//                          VT(:,j) = tau (v - VT w_v); block 0 also resets the
-//                          accumulators of the other parity and publishes the scalars.
+//   blocks [0, nshadow)  : the "shadow" blocks (32 rows each) -- V(:,j) = v and
+//                          VT(:,j) = tau (v - VT w_v); block 0 also publishes the scalars.
 //   remaining blocks     : gemv tiles, 512 rows (each lane owns an aligned row pair,
 //                          16-byte non-temporal loads: A is streamed once per column)
 //                          x one column chunk; the 4 waves of a workgroup read 4 KiB
@@ -387,18 +439,18 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
     double const *__restrict__ Y, double *__restrict__ t12,
     double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
-    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr, int fold = 0,
+    double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr,
     HessExchange x = HessExchange{}, int seq = 0)
 {
     __shared__ double s_wv[MAXJ], s_vrow[MAXJ], s_t[3][NGS][RBS + 1], s_scal[2];
     __shared__ int s_last;
-    int const piv = R0 + j, par = j & 1;
+    int const piv = R0 + j;
     double const *__restrict__ pcol = P + (size_t)j * ldp;
 
     if ((int)blockIdx.x < nshadow) {
         if (threadIdx.x == 0) {
             double scale, tau, beta;
-            reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+            reflector_scalars(nrm_sum(acc), pcol[piv], scale, tau, beta);
             s_scal[0] = scale; s_scal[1] = tau;
             if (blockIdx.x == 0) {   // published for colA(j+1) / finish
                 scal[4 * j + 0] = scale; scal[4 * j + 1] = tau; scal[4 * j + 2] = beta;
@@ -413,14 +465,9 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
         for (int l = tid; l < j; l += 256) {
             double const vr = V[(size_t)l * ldp + piv];                 // V(piv, l)
             s_vrow[l] = vr;
-            s_wv[l] = vr + scale * slot_sum(acc + ACC_WVSUM + par * NSLOT * MAXJ, l);
+            s_wv[l] = vr + scale * slot_sum(acc + ACC_WVSUM, l);
         }
         __syncthreads();
-        if (blockIdx.x == 0) {
-            for (int l = tid; l < NSLOT * MAXJ; l += 256)
-                acc[ACC_WVSUM + (par ^ 1) * NSLOT * MAXJ + l] = 0.0;
-            if (tid < NSLOT) acc[ACC_NRM + (par ^ 1) * NSLOT + tid] = 0.0;
-        }
         // a = VT(g, 0:j) w_v (for the new column of VT); ya = Y(g, 0:j) w_v and pa = Y(g, 0:j) V(piv, 0:j)^T:
         // the two products colA(j+1) needs from the columns of Y that exist already (see colA)
         double a = 0.0, ya = 0.0, pa = 0.0;
@@ -512,7 +559,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
         }
         }
         double scale, tau, beta;
-        reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+        reflector_scalars(nrm_sum(acc), pcol[piv], scale, tau, beta);
         if (!SHARD) {
             if (g >= R0) yp[g] = f0 + scale * (a0 + b0);
             if (g + 1 >= R0 && g + 1 < E) yp[g + 1] = f1 + scale * (a1 + b1);
@@ -521,21 +568,19 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             // (cdna_hip_programming.md section 6, Guideline 16, counter form): every partial is stored
             // write-through (sc1) and drained by its wave, the workgroup meets at its barrier, one lane
             // RELEASES at agent scope, takes the ticket, and the last arriver ACQUIRES at agent scope
-            // before any wave of it loads a partial (sc1 loads as well).  Rounds 3-4 relied on the sc1
-            // accesses alone (fold == 1; measured valid only for one workgroup per CU -- this launch
-            // keeps ~5 resident); the explicit release / acquire is correct for any placement.
+            // before any wave of it loads a partial (sc1 loads as well).  (Rounds 3-4 relied on the sc1
+            // accesses alone -- measured valid only for one workgroup per CU, this launch keeps ~5 resident;
+            // that form is gone.)
             if (g >= R0 && g < E) __hip_atomic_store(yp + g, f0 + scale * (a0 + b0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (g + 1 >= R0 && g + 1 < E) __hip_atomic_store(yp + g + 1, f1 + scale * (a1 + b1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int const nsplit = ((int)gridDim.x - nshadow) / row_tiles;
             if (threadIdx.x == 0) {
-                if (fold != 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler
-                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the fence's own wait can be dropped by the compiler
                 int const last = __hip_atomic_fetch_add(tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsplit - 1;
-                if (last && fold != 1) {
+                if (last) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // holds the barrier below until the invalidate is through
                 }
@@ -583,7 +628,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
             if (c == piv) { f = *a; c++; a += ldA; }
             for (; c < c_end; c++, a += ldA) s += (*a) * pcol[c];
             double scale, tau, beta;
-            reflector_scalars(nrm_sum(acc, par), pcol[piv], scale, tau, beta);
+            reflector_scalars(nrm_sum(acc), pcol[piv], scale, tau, beta);
             yp[g] = f + scale * s;
         }
     }
@@ -612,6 +657,8 @@ struct HessWorkspace {
     double *P = nullptr, *YVW[2] = {nullptr, nullptr}, *VT[2] = {nullptr, nullptr};
     double *S = nullptr, *W2 = nullptr;
     double *ypart = nullptr, *acc = nullptr, *scal = nullptr;
+    double *part = nullptr, *npart = nullptr;   // ordered sums of the column kernels: a partial vector (and a scalar) per workgroup
+    int *slot_cnt = nullptr;                    // their tickets: [0, NSLOT) colA, [NSLOT, 2 NSLOT) colC (self-resetting)
     double *t12 = nullptr;                      // [t1 | t2]: the products with the old columns of Y that colA(j+1) needs, formed in the shadow of gemv(j)
     static constexpr int MAX_ROW_TILES = HESS_MAX_ROW_TILES;    // row tiles of a gemv launch (512 rows each)
     int *tile_cnt = nullptr;                    // sharded gemv: arrivals per row tile (self-resetting)
@@ -627,9 +674,10 @@ struct HessWorkspace {
     std::vector<double> comm_payload;
 
     void release() {
-        double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal, &t12};
+        double **ptrs[] = {&P, &YVW[0], &YVW[1], &VT[0], &VT[1], &S, &W2, &ypart, &acc, &scal, &t12, &part, &npart};
         for (auto p : ptrs) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         if (tile_cnt) { SN_HIP_CHECK(hipFree(tile_cnt)); tile_cnt = nullptr; }
+        if (slot_cnt) { SN_HIP_CHECK(hipFree(slot_cnt)); slot_cnt = nullptr; }
         n = nbmax = 0; ysplits = 0;
     }
     // streams and events go when the owning thread lets the workspace go (node finalize, the end of a team
@@ -665,6 +713,11 @@ struct HessWorkspace {
         alloc(&acc, (size_t)ACC_TOTAL * sizeof(double));
         alloc(&scal, (size_t)4 * MAXJ * sizeof(double));
         alloc(&t12, (size_t)2 * ldp * sizeof(double));
+        int const nwg_max = divceil(n, RB) + 1;
+        alloc(&part, (size_t)nwg_max * MAXJ * sizeof(double));
+        alloc(&npart, (size_t)nwg_max * sizeof(double));
+        SN_HIP_CHECK(hipMalloc((void **)&slot_cnt, sizeof(int) * 2 * NSLOT));
+        SN_HIP_CHECK(hipMemset(slot_cnt, 0, sizeof(int) * 2 * NSLOT));
         SN_HIP_CHECK(hipMalloc((void **)&tile_cnt, sizeof(int) * MAX_ROW_TILES));
         SN_HIP_CHECK(hipMemset(tile_cnt, 0, sizeof(int) * MAX_ROW_TILES));
         if (!side) {
@@ -697,7 +750,9 @@ struct HessWorkspace {
 // multi-GPU path (node_team.hip) on one persistent thread per device
 static thread_local HessWorkspace g_ws;
 
-void hessenberg_release_workspace() { g_ws.release(); g_ws.destroy_streams(); }
+void dgemm_release_workspace();
+// (the scratch planes of the split-K products are keyed by stream: they go before the streams do)
+void hessenberg_release_workspace() { dgemm_release_workspace(); g_ws.release(); g_ws.destroy_streams(); }
 
 int hessenberg_panel_ld(int n, int) { return (int)roundup((size_t)n + GEMV_ROWS + 16, 128); }
 
@@ -738,6 +793,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
     SN_HIP_CHECK(hipEventRecord(ws.entry, caller));
     SN_HIP_CHECK(hipStreamWaitEvent(s, ws.entry, 0));
     if (tm) SN_HIP_CHECK(hipEventRecord(ws.ev0, s));
+    SN_HIP_CHECK(hipMemsetAsync(ws.slot_cnt, 0, sizeof(int) * 2 * NSLOT, s));    // (self-resetting; belt and braces)
     // profiling aid: stop after k panels (PMC runs cannot take 60 k dispatches); the result
     // is then a partial reduction and must not be used
     int const max_panels = tuning().hess_max_panels;
@@ -761,9 +817,9 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             int const piv = R0 + j;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, ws.P, VT, Y, ws.ypart, nsplit, ws.t12, ws.acc, ws.scal);
+                    R0, E, j, ldp, ws.P, VT, Y, ws.ypart, nsplit, ws.t12, ws.acc, ws.scal, ws.part, ws.slot_cnt);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
-                R0, E, j, ldp, ws.P, V, ws.acc);
+                R0, E, j, ldp, ws.P, V, ws.acc, ws.part, ws.npart, ws.slot_cnt + NSLOT);
             int const ncols = E - piv;
             choose_split(m, ncols, &nsplit, &cps);
             bool const sampled = sample_every > 0 && (gemv_launches % sample_every) == 0;
@@ -970,8 +1026,8 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     // with one rank there is nothing to reduce: the column chain reads the gemv's partials directly
     bool const reduce_y = world > 1;
     // how the column-split partials of the sharded gemv are folded: 0 in the launch, by the last workgroup of
-    // each row tile behind an agent-scope release / acquire; 1 the same on sc1 accesses alone (rounds 3-4, kept
-    // for the reproducer of tests/test_gpu_node_team.py); 2 by a launch of its own
+    // each row tile behind an agent-scope release / acquire; 2 by a launch of its own (the reproducer of
+    // scratch/r5_oversub.sh)
     int const fold = tuning().hess_fold;
     // the per-column all-reduce of y on the device (one-process team, common.h HessExchange): column number
     // `seq` (counted across reductions: the flags are never reset) selects the parity of the slots
@@ -979,6 +1035,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
     HessExchange const x = dev_x ? *comm.exchange : HessExchange{};
     int seq = x.seq_base;
     if (reduce_y && aligned) SN_HIP_CHECK(hipMemsetAsync(ws.tile_cnt, 0, sizeof(int) * HessWorkspace::MAX_ROW_TILES, s));
+    SN_HIP_CHECK(hipMemsetAsync(ws.slot_cnt, 0, sizeof(int) * 2 * NSLOT, s));
     // measurement (bench.py at N > 1): HIP events on the reduction's stream around every k-th gemv launch
     // and its all-reduce, around the per-panel collectives and the assembly
     int const sample_every = tm ? tm->sample_every : 0;
@@ -1036,9 +1093,9 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             double const *ysrc = reduce_y ? dYsum : ws.ypart;
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
-                    R0, E, j, ldp, dP, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.t12, ws.acc, ws.scal, x, seq);
+                    R0, E, j, ldp, dP, VT, Ys, ysrc, reduce_y ? 1 : nsplit, ws.t12, ws.acc, ws.scal, ws.part, ws.slot_cnt, x, seq);
             hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
-                R0, E, j, ldp, dP, V, ws.acc);
+                R0, E, j, ldp, dP, V, ws.acc, ws.part, ws.npart, ws.slot_cnt + NSLOT);
             seq++;              // the number of THIS column's gemv
             // owned column blocks that intersect [piv, E): the splits of this rank's share of the gemv
             int const b0 = piv / cb;
@@ -1058,7 +1115,7 @@ int hessenberg_sharded_device(hipStream_t s, int n, int panel_width,
             if (aligned && reduce_y && fold != 2)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, true, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,
-                    world, rank, dYsum, ws.tile_cnt, fold, x, seq);
+                    world, rank, dYsum, ws.tile_cnt, x, seq);
             else if (aligned)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true>), grid, dim3(256), 0, s,
                     dA, ldA, dP, R0, E, j, cb, ldp, nshadow, row_tiles, ws.ypart, V, VT, Ys, ws.t12, ws.acc, ws.scal,

@@ -13,9 +13,11 @@
 //   rows in LDS: no solve with B, singular B included), applied to the columns of B, A.  Sweep j + 1 runs position
 //   t while sweep j runs position t + 2: wavefronts of ~n / (2 r) independent steps, three launches each (left
 //   reflectors; opposite reflectors under the left application; right application).  Q and Z take the reflectors
-//   of 64 sweeps at a time as compact-WY blocks on a second stream.
-// scratch/ht2_proto.py and scratch/ht2_lag.py are the numpy statements of the algorithm and of this order
-// (tests/test_ht_twostage_prototype.py).
+//   of 64 sweeps at a time as compact-WY blocks on a second stream -- and so do the rows of A and B ABOVE the first
+//   row a group's left reflectors can reach (round 6): those rows only ever see right reflectors again, half of the
+//   right application's bytes leave the chase.
+// scratch/ht2_proto.py, scratch/ht2_lag.py and scratch/ht2_defer.py are the numpy statements of the algorithm, of this
+// order and of the deferred rows (tests/test_ht_twostage_prototype.py).
 #include "common.h"
 #include "tuning.h"
 #include <algorithm>
@@ -353,10 +355,17 @@ __device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chun
     }
 }
 
-// X(0:rows, p:p1) <- X (I - tau v v^T) for up to three targets: a workgroup takes 64 rows, wave q of its four the
+// X(top:rows, p:p1) <- X (I - tau v v^T) for up to three targets: a workgroup takes 64 rows, wave q of its four the
 // columns 16 q .. 16 q + 15 of the block (lane = row: every load is 512 contiguous bytes), the partial row sums
-// meet in LDS.  kind 0: all nrows rows (Q, Z); kind 1: rows [0, p1) and the first column of the block cleaned
-// below its diagonal entry (B after the opposite reflector); kind 2: rows [0, min(p1 + r, n)) (A).
+// meet in LDS.  kind 0: all nrows rows (Q, Z); kind 1: rows [top, p1) and the first column of the block cleaned
+// below its diagonal entry (B after the opposite reflector); kind 2: rows [top, min(p1 + r, n)) (A).
+// top = (j / GS) GS + 1 (kinds 1, 2): the rows above the first row any left reflector of the sweep's GROUP -- or of a
+// later one -- can reach.  From the group's first wavefront on they see right reflectors only (a sweep j' of an
+// older group is at p' = j' + 1 + (tau - 2 j') r >= top by then), so they take the group's opposite reflectors
+// later, as compact-WY blocks beside Z (close_group): the blocks of OLDER groups that overlap one of them in columns
+// were generated, and applied to these rows at once, before it; later ones are disjoint from it
+// (scratch/ht2_defer.py runs this order in numpy, and the same deferral of the LEFT reflectors' far columns as the
+// negative control: a right reflector that straddles the boundary mixes updated and stale columns).
 struct RightTargets { double *X[3]; int ld[3]; int kind[3]; };
 __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTargets tg, int nrows,
     double const *__restrict__ RV, double const *__restrict__ RT)
@@ -370,10 +379,12 @@ __global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTarg
     double *X = tg.X[z];
     int const ld = tg.ld[z], kind = tg.kind[z];
     int const rows = kind == 0 ? nrows : (kind == 1 ? p1 : min(p1 + R2, w.n));
-    if (blockIdx.x * 64 >= rows) return;
+    // (row tiles start on a multiple of 16 rows at or below top: 128-byte lines; the rows below top are masked)
+    int const top = kind == 0 ? 0 : ((w.jlo + k) / GS) * GS + 1, base = top & ~15;
+    if (base + blockIdx.x * 64 >= rows) return;
     int const lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    int const row = blockIdx.x * 64 + lane, q0 = 16 * part;
-    bool const live = row < rows;
+    int const row = base + blockIdx.x * 64 + lane, q0 = 16 * part;
+    bool const live = row < rows && row >= top;
     double *x = X + (size_t)(p + q0) * ld + row;
     if (tau != 0.0) {
         double y[16], v[16], d = 0.0;
@@ -556,7 +567,7 @@ constexpr int WY_T = 512, WY_SLAB = 32;
 constexpr int WY_LDV = 2 * R2 + 1, WY_LDW = R2 + 1, WY_LDR = WY_SLAB + 1;
 constexpr int WY_LEFT_LDS = (R2 * WY_LDV + WY_SLAB * WY_LDV + WY_SLAB * WY_LDW) * 8;
 constexpr int WY_RIGHT_LDS = (R2 * WY_LDV + 2 * R2 * WY_LDR + R2 * WY_LDR) * 8;
-struct WyTargets { double *X[2]; int ld[2]; int extent[2]; };      // extent: columns (left) / rows (right)
+struct WyTargets { double *X[3]; int ld[3]; int extent[3]; };      // extent: columns (left) / rows (right)
 
 // a factor (2 r x r, leading dimension 2 r, zero beyond m rows and k columns) into registers -- every load in flight
 // at once, and V T^T on its way while W is still being formed from V -- and from there into LDS
@@ -689,8 +700,6 @@ struct Ht2Workspace {
     int maxcount = 0;
     bool attr = false;
     hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
-    hipStream_t cstream[3] = {};                    // stage 2: the chains of sweeps beside the caller's stream
-    hipEvent_t lr[4] = {};
     hipEvent_t ready[RING] = {}, used[RING] = {}, used_s[RING] = {}, ready_r[RING] = {}, used_r[RING] = {}, column = nullptr, tail = nullptr;
     hipEvent_t through[MAXSLOT] = {}, applied[MAXSLOT] = {};
     void ensure(int n_)
@@ -719,8 +728,6 @@ struct Ht2Workspace {
                 std::vector<uint32_t> mask(words, 0xffffffffu);
                 SN_HIP_CHECK(hipExtStreamCreateWithCUMask(&pstream, words, mask.data()));
             }
-            for (int k = 0; k < 3; k++) SN_HIP_CHECK(hipStreamCreateWithFlags(&cstream[k], hipStreamNonBlocking));
-            for (int k = 0; k < 4; k++) SN_HIP_CHECK(hipEventCreateWithFlags(&lr[k], hipEventDisableTiming));
             for (int k = 0; k < MAXSLOT; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&through[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&applied[k], hipEventDisableTiming));
@@ -757,7 +764,7 @@ void wy_left(hipStream_t s, double const *V, double const *VT, int m, int k, dou
     int const widest = std::max(ncols0, ncols1);
     if (widest <= 0) return;
     hipLaunchKernelGGL(ht2_wy_left_kernel, dim3(divceil(widest, WY_SLAB), X1 ? 2 : 1), dim3(WY_T), WY_LEFT_LDS, s, V, VT, m, k,
-        WyTargets{{X0, X1}, {ld0, ld1}, {ncols0, ncols1}});
+        WyTargets{{X0, X1, nullptr}, {ld0, ld1, 0}, {ncols0, ncols1, 0}});
 }
 // X_z (nrows_z x m) <- X_z (I - V T V^T)
 void wy_right(hipStream_t s, double const *V, double const *VT, int m, int k, double *X0, int ld0, int nrows0,
@@ -768,12 +775,33 @@ void wy_right(hipStream_t s, double const *V, double const *VT, int m, int k, do
     int const tallest = std::max(nrows0, nrows1);
     if (tallest <= 0) return;
     hipLaunchKernelGGL(ht2_wy_right_kernel, dim3(divceil(tallest, WY_SLAB), X1 ? 2 : 1), dim3(WY_T), WY_RIGHT_LDS, s, V, VT, m, k,
-        WyTargets{{X0, X1}, {ld0, ld1}, {nrows0, nrows1}});
+        WyTargets{{X0, X1, nullptr}, {ld0, ld1, 0}, {nrows0, nrows1, 0}});
+}
+// the same for any subset of three targets (NULL or no rows: skipped), one launch
+void wy_right3(hipStream_t s, double const *V, double const *VT, int m, int k, WyTargets tg)
+{
+    if (k <= 0) return;
+    WyTargets live{{nullptr, nullptr, nullptr}, {0, 0, 0}, {0, 0, 0}};
+    int cnt = 0, tallest = 0;
+    for (int z = 0; z < 3; z++)
+        if (tg.X[z] && tg.extent[z] > 0) {
+            live.X[cnt] = tg.X[z]; live.ld[cnt] = tg.ld[z]; live.extent[cnt] = tg.extent[z];
+            tallest = std::max(tallest, tg.extent[z]); cnt++;
+        }
+    if (cnt == 0) return;
+    hipLaunchKernelGGL(ht2_wy_right_kernel, dim3(divceil(tallest, WY_SLAB), cnt), dim3(WY_T), WY_RIGHT_LDS, s, V, VT, m, k, live);
 }
 
 } // namespace
 
 void ht_two_stage_release_workspace() { g_ht2.release(); }
+
+// Can the two-stage path take this n?  (The slots of the reflector store bound the groups of sweeps in flight:
+// MAXSLOT = 16 covers n < ~100 000; the caller falls back to the rotation path otherwise.)
+bool ht_two_stage_fits(int n)
+{
+    return n >= 3 && (ht2_tstride(n) + LAG * GS - LAG) / (LAG * GS) + 2 <= MAXSLOT;
+}
 
 // (A, B), B upper triangular -> Hessenberg-triangular, Q <- Q U1, Z <- Z U2 (Q, Z may be NULL).  The reduction
 // of A and B runs on `s`; Q and Z -- nothing reads them before the end -- take their transformations on `sq`
@@ -785,6 +813,32 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     ws.ensure(n);
     int const r = R2;
     if (!sq) sq = s;
+    // the wavefronts of stage 2: sweeps jlo .. jlo + count - 1 of wavefront tau_idx (position t = tau_idx - LAG j must
+    // satisfy j + 1 + t r <= n - 2); a group of GS sweeps is through with the last step of its last sweep
+    int const tstride = ht2_tstride(n), nslot = ht2_nslot(n), ngroups = (n - 2 + GS - 1) / GS;
+    auto wavefront = [&](int tau_idx, int &jlo, int &count) {
+        int const jhi = std::min(tau_idx / LAG, n - 3);
+        long const num = (long)tau_idx * r - (n - 3);
+        jlo = num <= 0 ? 0 : (int)((num + (LAG * r - 1) - 1) / (LAG * r - 1));
+        count = jhi - jlo + 1;
+        return jlo <= jhi;
+    };
+    auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return LAG * jl + (n - 3 - jl) / R2; };
+    // Everything that can refuse the problem depends on n alone and is checked BEFORE the first launch: the steps
+    // of a wavefront must fit the scratch of their copied blocks, the groups in flight the slots of the reflector
+    // store (a dry run of the wavefront loop; an error return in the middle of it would leave kernels enqueued on
+    // three streams and A, B scaled)
+    {
+        int opened = 0, closed = 0;
+        for (int tau_idx = 0;; tau_idx++) {
+            int jlo, count;
+            if (!wavefront(tau_idx, jlo, count)) { if (tau_idx / LAG >= n - 3) break; else continue; }
+            if (count > ws.maxcount) return -1;
+            opened = std::max(opened, (jlo + count - 1) / GS + 1);
+            if (opened - closed > nslot) return -2;
+            while (closed < ngroups && last_wave(closed) <= tau_idx) closed++;
+        }
+    }
     // ---- stage 1 -----------------------------------------------------------------------------------------------
     // Three streams.  The QR factorisations of a block column's panels touch the panel's columns only, and nothing
     // else does until the next block column: they run ahead on `sp`, a ring of factor slots (V, V T^T) between them
@@ -851,78 +905,51 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     }
     if (between) SN_HIP_CHECK(hipEventRecord(between, s));
     // ---- stage 2 -----------------------------------------------------------------------------------------------
-    int const tstride = ht2_tstride(n), nslot = ht2_nslot(n), ngroups = (n - 2 + GS - 1) / GS;
-    int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q and Z
-    // the last wavefront with a step of group g: its last sweep jl at its last position
-    auto last_wave = [&](int g) { int const jl = std::min(g * GS + GS - 1, n - 3); return LAG * jl + (n - 3 - jl) / R2; };
     // The steps of a wavefront are independent; a step depends on its own sweep's previous step and on OLDER sweeps'
-    // steps of the wavefronts before.  The active sweeps are dealt, oldest first, to C chains, each on its own
-    // stream: generation of the reflectors (one workgroup a step, 75 us of latency, no memory traffic to speak of),
-    // then the two wide applications (HBM bound).  The applications of all chains are serialised round robin by
-    // events -- left and right reflectors of different steps meet in common entries --, so what the chains buy is
-    // the generation of one chain under the applications of the others.  A sweep that changes chain (the boundaries
-    // move as old sweeps finish) waits for the whole previous wavefront.
-    int const C = tuning().ht2_chains;
-    hipStream_t const cs[4] = {s, ws.cstream[0], ws.cstream[1], ws.cstream[2]};
-    SN_HIP_CHECK(hipEventRecord(ws.column, s));
-    for (int c = 1; c < C; c++) SN_HIP_CHECK(hipStreamWaitEvent(cs[c], ws.column, 0));
-    hipEvent_t last_ev = nullptr, prev_wave_last = nullptr;
-    hipStream_t last_stream = s;
-    int prev_top[4] = {-1, -1, -1, -1}, prev_cnt[4] = {0, 0, 0, 0};
+    // steps of the wavefronts before.  Three launches a wavefront on `s`: the left reflectors (one small workgroup a
+    // step), the opposite reflectors (75 us of latency, one workgroup a step) under the left application, the right
+    // application.  (Dealing the sweeps of a wavefront to 2-4 streams so that one chain's generation hides under the
+    // others' applications was correct and 2.5 x slower -- every hand-over between streams is 11 us of a loop the
+    // host already bounds; round 5; removed.)
+    int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q, Z and the top rows
     auto close_group = [&](int g) {
         int const j0 = g * GS, gsize = std::min(GS, n - 2 - j0), slot = g % nslot;
         int const tcount = (n - 3 - j0) / R2 + 1;
-        if (Q || Z) {
-            if (sq != last_stream) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], last_stream)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
-            hipLaunchKernelGGL(ht2_group_wy_kernel, dim3(tcount, 2), dim3(QT), GROUP_LDS_BYTES, sq, n, j0, gsize, tstride, slot,
-                ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.VTb);
-            for (int t = tcount - 1; t >= 0; t--) {
-                int const col0 = j0 + 1 + R2 * t, k = std::min(gsize, n - 1 - col0);
-                if (k <= 0) continue;
-                int const m = std::min(k - 1 + R2, n - col0);
-                if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.VTb + (size_t)t * 2 * R2 * R2, m, k,
-                    Q + (size_t)col0 * ldq, ldq, n);
-                if (Z) wy_right(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, m, k,
-                    Z + (size_t)col0 * ldz, ldz, n);
-            }
-            if (sq != s || C > 1) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
+        int const top = j0 + 1;             // rows [0, top) of A and B: the group's opposite reflectors are still due
+        if (sq != s) { SN_HIP_CHECK(hipEventRecord(ws.through[slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.through[slot], 0)); }
+        hipLaunchKernelGGL(ht2_group_wy_kernel, dim3(tcount, 2), dim3(QT), GROUP_LDS_BYTES, sq, n, j0, gsize, tstride, slot,
+            ws.HV, ws.HT, ws.GV, ws.GT, ws.Vb, ws.VTb);
+        for (int t = tcount - 1; t >= 0; t--) {
+            int const col0 = j0 + 1 + R2 * t, k = std::min(gsize, n - 1 - col0);
+            if (k <= 0) continue;
+            int const m = std::min(k - 1 + R2, n - col0);
+            if (Q) wy_right(sq, ws.Vb + (size_t)t * 2 * R2 * R2, ws.VTb + (size_t)t * 2 * R2 * R2, m, k,
+                Q + (size_t)col0 * ldq, ldq, n);
+            // the opposite reflectors: Z, and the rows of A and B the chase left to this pass (ht2_apply_right_kernel)
+            wy_right3(sq, ws.Vb + (size_t)(tstride + t) * 2 * R2 * R2, ws.VTb + (size_t)(tstride + t) * 2 * R2 * R2, m, k,
+                WyTargets{{Z ? Z + (size_t)col0 * ldz : nullptr, A + (size_t)col0 * lda, B + (size_t)col0 * ldb},
+                          {ldz, lda, ldb}, {n, top, top}});
         }
+        if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
     };
     for (int tau_idx = 0;; tau_idx++) {
-        int const jhi = std::min(tau_idx / LAG, n - 3);
-        // position t = tau_idx - LAG j must satisfy j + 1 + t r <= n - 2
-        long const num = (long)tau_idx * r - (n - 3);
-        int const jlo = num <= 0 ? 0 : (int)((num + (LAG * r - 1) - 1) / (LAG * r - 1));
-        if (jlo > jhi) { if (tau_idx / LAG >= n - 3) break; else continue; }
-        int const count = jhi - jlo + 1;
+        int jlo, count;
+        if (!wavefront(tau_idx, jlo, count)) { if (tau_idx / LAG >= n - 3) break; else continue; }
+        int const jhi = jlo + count - 1;
         for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
-            if (opened >= nslot && (sq != s || C > 1) && (Q || Z))
-                for (int c = 0; c < C; c++) SN_HIP_CHECK(hipStreamWaitEvent(cs[c], ws.applied[opened % nslot], 0));
-        if (opened - closed > nslot) return -2;
-        for (int c = 0; c < C; c++) {
-            int const b0 = jlo + (int)((long)count * c / C), b1 = jlo + (int)((long)count * (c + 1) / C), cnt = b1 - b0;
-            if (cnt <= 0) { prev_cnt[c] = 0; continue; }
-            hipStream_t const st = cs[c];
-            bool const moved = prev_cnt[c] == 0 || (c < C - 1 && b1 > prev_top[c]);
-            if (moved && prev_wave_last && C > 1) SN_HIP_CHECK(hipStreamWaitEvent(st, prev_wave_last, 0));
-            Wave2 const w{n, tau_idx, b0, cnt, tstride, nslot};
-            if (last_ev && last_stream != st) SN_HIP_CHECK(hipStreamWaitEvent(st, last_ev, 0));
-            if (cnt > ws.maxcount) return -1;
-            int const nchunk = divceil(n, LEFT_CHUNK);
-            hipLaunchKernelGGL(ht2_genh_kernel, dim3(cnt), dim3(256), 0, st, w, A, lda, B, ldb, ws.HV, ws.HT, ws.Bcopy);
-            hipLaunchKernelGGL(ht2_geng_left_kernel, dim3(cnt + cnt * 2 * nchunk), dim3(QT), GEN_LDS_BYTES, st, w, nchunk, A, lda, B, ldb,
-                ws.HV, ws.HT, ws.GV, ws.GT, ws.Bcopy);
-            hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n, 64), cnt, 2), dim3(256), 0, st, w,
-                RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
-            if (C > 1) { SN_HIP_CHECK(hipEventRecord(ws.lr[c], st)); last_ev = ws.lr[c]; }
-            last_stream = st;
-            prev_top[c] = b1; prev_cnt[c] = cnt;
-        }
-        prev_wave_last = last_ev;
+            if (opened >= nslot && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.applied[opened % nslot], 0));
+        Wave2 const w{n, tau_idx, jlo, count, tstride, nslot};
+        int const nchunk = divceil(n, LEFT_CHUNK);
+        hipLaunchKernelGGL(ht2_genh_kernel, dim3(count), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT, ws.Bcopy);
+        hipLaunchKernelGGL(ht2_geng_left_kernel, dim3(count + count * 2 * nchunk), dim3(QT), GEN_LDS_BYTES, s, w, nchunk, A, lda, B, ldb,
+            ws.HV, ws.HT, ws.GV, ws.GT, ws.Bcopy);
+        // (the oldest sweep of the wavefront has the smallest top: its row tiles bound the grid)
+        int const base = ((jlo / GS) * GS + 1) & ~15;
+        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n - base, 64), count, 2), dim3(256), 0, s, w,
+            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
         for (; closed < ngroups && last_wave(closed) <= tau_idx; closed++) close_group(closed);
     }
     for (; closed < ngroups; closed++) close_group(closed);
-    if (last_stream != s && last_ev) SN_HIP_CHECK(hipStreamWaitEvent(s, last_ev, 0));
     if (sq != s) {
         SN_HIP_CHECK(hipEventRecord(ws.tail, sq));
         SN_HIP_CHECK(hipStreamWaitEvent(s, ws.tail, 0));

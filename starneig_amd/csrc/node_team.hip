@@ -62,6 +62,9 @@ bool rank_fits(int rank, int n)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
     if (tuning().team_fail_rank == rank) free_b = 0;    // tests: this rank "cannot allocate"
+    // the same, switchable between two calls of one process (a success - failure - success sequence must leave the
+    // device-side exchange consistent); read here, once per reduction and rank, not on any hot path
+    if (tuning().team_fail_rank == -2) { char const *e = getenv("SN_TEAM_FAIL_RANK_NOW"); if (e && atoi(e) == rank) free_b = 0; }
     double const mat = (double)roundup(n, 16) * n * sizeof(double);
     double const need = 2 * mat + 0.7 * mat + 1e9;
     if (need <= (double)free_b) return true;
@@ -121,6 +124,7 @@ struct Team {
     // device-side exchange of the per-column vectors of the sharded Hessenberg reduction (common.h HessExchange):
     // per rank a flag array for the life of the team, a slot buffer per call, an error word
     bool device_exchange = false;
+    bool exchange_needs_finegrained = false;    // ranks on distinct devices: flags and slots must be fine-grained memory
     int *xflags[MAX_RANKS] = {};
     double *xslots[MAX_RANKS] = {};
     long xslots_cap[MAX_RANKS] = {};
@@ -244,14 +248,17 @@ struct Team {
             });
             if (unreachable.load() > 0) device_exchange = false;
         }
+        exchange_needs_finegrained = distinct;
         if (device_exchange) {
             std::atomic<int> failed{0};
             run([&](int rank) {
                 size_t const bytes = (size_t)MAX_RANKS * HESS_MAX_ROW_TILES * sizeof(int) + 64;
-                // fine-grained: written by peers, polled by this device's kernels
+                // fine-grained: written by peers, polled by this device's kernels.  Without it the exchange is only
+                // used between ranks of ONE device (agent scope suffices there); between distinct devices the team
+                // falls back to the host / RCCL exchange (failed -> device_exchange = false below)
                 if (hipExtMallocWithFlags((void **)&xflags[rank], bytes, hipDeviceMallocFinegrained) != hipSuccess) {
                     (void)hipGetLastError();
-                    if (hipMalloc((void **)&xflags[rank], bytes) != hipSuccess) { (void)hipGetLastError(); xflags[rank] = nullptr; failed++; return; }
+                    if (distinct || hipMalloc((void **)&xflags[rank], bytes) != hipSuccess) { (void)hipGetLastError(); xflags[rank] = nullptr; failed++; return; }
                 }
                 SN_HIP_CHECK(hipMemset(xflags[rank], 0, bytes));
             });
@@ -365,6 +372,12 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
     int const ld = (int)roundup(n, 16), ldp = hessenberg_panel_ld(n, panel_width);
     int const threads = std::max(1, cores / world);
     std::atomic<int> failures{0};
+    // The flags of the device-side exchange hold the sequence number of the last exchanged column.  seq_base goes
+    // back to 0 ONLY together with flags zeroed on every rank (the late failure path below); a call that leaves
+    // before the first column was exchanged (allocation failure) changes neither -- with seq_base reset over
+    // flags that still hold ~seq_base + n the next reduction's waits would all be satisfied at once and its
+    // column kernels would sum slots the peers have not written yet.
+    std::atomic<int> flags_zeroed{0};
     T.run([&](int rank) {
         hipStream_t s = T.stream[rank];
         size_t const bytes = (size_t)ld * n * 8;
@@ -402,7 +415,11 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
                 T.xslots[rank] = nullptr; T.xslots_cap[rank] = 0;
                 if (hipExtMallocWithFlags((void **)&T.xslots[rank], (size_t)need * 8, hipDeviceMallocFinegrained) != hipSuccess) {
                     (void)hipGetLastError();
-                    SN_TEAM_TRY(hipMalloc((void **)&T.xslots[rank], (size_t)need * 8), failures);
+                    // coarse-grained memory only where every rank sits on ONE device (the virtual ranks of the test
+                    // box): between distinct devices system-scope visibility of flags and data needs fine-grained
+                    // memory, and the team does not start the device exchange without it (Team::start)
+                    if (T.exchange_needs_finegrained) { T.xslots[rank] = nullptr; failures++; }
+                    else SN_TEAM_TRY(hipMalloc((void **)&T.xslots[rank], (size_t)need * 8), failures);
                 }
                 if (T.xslots[rank]) T.xslots_cap[rank] = need;
             }
@@ -428,8 +445,10 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
         }
         if (r != 0) failures++;
         T.bar.wait();                                   // a failed rank: nobody overwrites the caller's arrays
-        if (failures.load() > 0 && T.device_exchange && T.xflags[rank])    // the exchange starts from scratch next time
+        if (failures.load() > 0 && T.device_exchange && T.xflags[rank]) {  // the exchange starts from scratch next time
             SN_HIP_CHECK(hipMemset(T.xflags[rank], 0, (size_t)MAX_RANKS * HESS_MAX_ROW_TILES * sizeof(int) + 64));
+            flags_zeroed++;
+        }
         if (failures.load() == 0) {
             int const per = divceil(n, world), c0 = std::min(n, rank * per), c1 = std::min(n, c0 + per);
             if (c1 > c0) {
@@ -439,7 +458,11 @@ int node_team_hessenberg(int n, int panel_width, double *A, int ldA, double *Q, 
         }
         for (double *p : {dA, dQ, dY, dP, dW}) SN_HIP_CHECK(hipFree(p));
     });
-    if (T.device_exchange) T.seq_base = failures.load() == 0 ? T.seq_base + n - 1 : 0;   // one exchange per reduced column, on every rank
+    if (T.device_exchange) {
+        if (failures.load() == 0) T.seq_base += n - 1;              // one exchange per reduced column, on every rank
+        else if (flags_zeroed.load() == world) T.seq_base = 0;      // every rank's flags are zero again
+        // else: the team left before the first exchange, flags and seq_base still belong together
+    }
     return failures.load() == 0 ? 0 : 1;
 }
 

@@ -48,12 +48,7 @@ constexpr int UPDATE_LDS_BYTES_L = GemmCfg<WS_MAX, 128, 16, true, false>::LDS_BY
 constexpr int UPDATE_LDS_BYTES_R = GemmCfg<128, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_R64 = GemmCfg<64, WS_MAX, 16, false, false>::LDS_BYTES;
 constexpr int UPDATE_LDS_BYTES_P = UPDATE_LDS_BYTES_L > UPDATE_LDS_BYTES_R ? UPDATE_LDS_BYTES_L : UPDATE_LDS_BYTES_R;
-constexpr int CHASE_LDS_BYTES_WU = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // rounds 1-4: W and U in LDS, two reflector buffers (150 KB)
-// Round 5: the accumulated factor U lives in REGISTERS (three entries per (bulge, row) pair, handed from bulge
-// to bulge by DPP row shifts, finished columns stored straight to HBM): the window alone is 75 KB, so that a
-// chase workgroup fits on a CU BESIDE one update workgroup (64.5 KB each, two per CU) instead of waiting for an
-// empty CU -- profiles/r4_chase_in_situ.txt: 184 us per launch in situ against 97 us alone.
-constexpr int CHASE_LDS_BYTES = (WS_MAX * LDW + 12 * NB_MAX + 16) * 8;
+constexpr int CHASE_LDS_BYTES_WU = (2 * WS_MAX * LDW + 12 * NB_MAX + 16) * 8;   // window W and accumulated factor U in LDS, two reflector buffers (150 KB)
 
 // LAPACK dlaqr1 for a 3x3 block: first column of (H - s1 I)(H - s2 I), scaled
 __device__ __forceinline__ void shift_vector(double const *W, double sr1, double si1,
@@ -119,28 +114,15 @@ __device__ __forceinline__ ChaseReflector chase_build(double *W, int n, int i, i
     return ChaseReflector{v1, v2, tau, j + 1, (tau != 0.0) ? len : 0};
 }
 
-// one lane's value to the lane below it in its 16-lane DPP row (lane k receives lane k + 1's; the last lane 0)
-__device__ __forceinline__ double dpp_row_shl1(double x)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, true);     // row_shl:1, bound_ctrl
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-// the accumulated factor in registers (UREG): one (bulge i, row r) item holds U(r, row0 .. row0 + 2), the
-// three columns of the bulge's current position
-struct UItem {
-    double u0, u1, u2;
-    int r;          // row of U, -1: no item
-};
-
-template <int DBG, bool UREG, int CHASE_THREADS = 1024>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
+// (Round 5 built and measured two variants with the accumulated factor in registers instead of LDS -- 75 KB of LDS
+// a window, 1024 and 512 threads: bit-identical results, 101 / 122 us a launch alone against 98 us, the Schur leg
+// 1.67-1.72 s with all three; profiles/r5_chase_variants.txt, DESIGN.md section 4 -- and round 6 removed them.)
+template <int DBG>      // DBG != 0: timing experiments of scratch/chase_bench.py (phases switched off)
 __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *W = lds, *U = lds + WS_MAX * LDW, *Rbase = U + (UREG ? 0 : WS_MAX * LDW);   // per bulge {v1,v2,tau,-}, two buffers
+    double *W = lds, *U = lds + WS_MAX * LDW, *Rbase = U + WS_MAX * LDW;   // per bulge {v1,v2,tau,-}, two buffers
     int *Ribase = reinterpret_cast<int *>(Rbase + 8 * NB_MAX);            // per bulge {row0, len}, two buffers
     ChaseTask const t = make_task(step, blockIdx.x);
     int const n = t.n, nb = t.nb, tid = threadIdx.x;
@@ -150,28 +132,12 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
     for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         W[c * LDW + r] = H[(size_t)(t.lo + c) * ldH + t.lo + r];
-        if (!UREG) U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
+        U[c * LDW + r] = (r == c) ? 1.0 : 0.0;
     }
     // the (bulge, column) and (bulge, row) pairs a lane owns do not change from step to step
     constexpr int L_ITEMS = (NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
-    constexpr int R_ITEMS = ((UREG ? 1 : 2) * NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
-    int const rspan = UREG ? n : 2 * n;                                  // items per bulge of the right phase
-    // UREG: lane = bulge i (0..15) + 16 * (row & 3); waves 0..15 hold rows 4w .. 4w + 3, waves 8..15 rows
-    // 32 + 4w .. as well (96 rows = 24 groups of four): the hand-off of an entry from bulge i + 1 to bulge i
-    // is a DPP shift inside a 16-lane row
-    int const ui = tid & 15, usub = (tid >> 4) & 3, uw = tid >> 6;
-    constexpr int UNW = CHASE_THREADS / 64;                              // waves; 4 rows per wave and set
-    constexpr int USETS = (WS_MAX + 4 * UNW - 1) / (4 * UNW);            // 16 waves: 2 sets (the second on waves 8..15), 8 waves: 3
-    UItem uu[USETS];
-    #pragma unroll
-    for (int k = 0; k < USETS; k++) {
-        uu[k] = UItem{0.0, 0.0, 0.0, -1};
-        if (UREG) {
-            int const wk = (UNW == 16 && k == 1) ? uw - 8 : uw;          // (16 waves: rows 64..95 on waves 8..15, wave 0 carries the chain)
-            int const r = k * 4 * UNW + 4 * wk + usub;
-            if (ui < nb && wk >= 0 && r < n) uu[k].r = r;
-        }
-    }
+    constexpr int R_ITEMS = (2 * NB_MAX * WS_MAX + CHASE_THREADS - 1) / CHASE_THREADS;
+    int const rspan = 2 * n;                                             // items per bulge of the right phase: window rows, rows of U
     int li[L_ITEMS], lc[L_ITEMS], ri[R_ITEMS], rr_[R_ITEMS];
     #pragma unroll
     for (int k = 0; k < L_ITEMS; k++) {
@@ -187,18 +153,6 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
 
     int const left = introduce ? 2 - 3 * nb : 0;
     int const right = finalize ? n - 2 : t.right;
-    if (UREG) {
-        // U = I: the entries of the bulges' first positions; the columns left of bulge 0's first position are final
-        int const c0 = left + 3 * ui + 1;
-        #pragma unroll
-        for (int k = 0; k < USETS; k++) {
-            uu[k].u0 = (uu[k].r == c0) ? 1.0 : 0.0; uu[k].u1 = (uu[k].r == c0 + 1) ? 1.0 : 0.0; uu[k].u2 = (uu[k].r == c0 + 2) ? 1.0 : 0.0;
-        }
-        for (int idx = tid; idx < (left + 1) * n; idx += CHASE_THREADS) {       // (left + 1 <= 0 at an introduction)
-            int const r = idx % n, c = idx / n;
-            Uo[c * WS_MAX + r] = (r == c) ? 1.0 : 0.0;
-        }
-    }
     ChaseReflector mine{0.0, 0.0, 0.0, 0, 0};
     double sr1 = 0.0, si1 = 0.0, sr2 = 0.0, si2 = 0.0;         // the lane's shift pair (used at introduction)
     if (tid < nb && introduce) {
@@ -269,7 +223,7 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
             if (i < 0 || (DBG & 2)) continue;
             int const row0 = begin + 3 * i + 1;
             int const cs = max(0, min(max(row0, 0), n - 3));            // clamped column for the reads
-            bool const inW = UREG || rr < n;
+            bool const inW = rr < n;
             int const r = inW ? rr : rr - n;
             double *M = inW ? W : U;
             double *p = M + cs * LDW + r;
@@ -284,84 +238,23 @@ __device__ __forceinline__ void schur_chase_body(SweepStep const step, double *_
             q[0] = y0 - sum; q[LDW] = y1 - sum * rf.x;
             if (len == 3) q[2 * LDW] = y2 - sum * rf.y;
         }
-        if (UREG && !(DBG & 2)) {
-            // the accumulated factor: this step's reflector of bulge ui on the three entries each item holds;
-            // then the bulge moves one column on -- its first entry goes to bulge ui - 1 (whose position it
-            // enters; from bulge 0: out to HBM, that column is final), a new one comes from bulge ui + 1 (from
-            // the identity for the leading bulge)
-            d4 const rf = *reinterpret_cast<d4 const *>(R + 4 * min(ui, NB_MAX - 1));
-            int const len = (ui < nb) ? (int)rf.w : 0;
-            int const row0 = begin + 3 * ui + 1;
-            bool const move = begin + 1 < right;
-            #pragma unroll
-            for (int which = 0; which < USETS; which++) {
-                UItem &it = uu[which];
-                if (len != 0 && it.r >= 0) {
-                    double const y2 = (len == 3) ? it.u2 : 0.0;
-                    double const sum = rf.z * (it.u0 + rf.x * it.u1 + rf.y * y2);
-                    it.u0 -= sum; it.u1 -= sum * rf.x;
-                    if (len == 3) it.u2 -= sum * rf.y;
-                }
-                if (move) {     // (uniform: every lane of the wave takes part in the shift)
-                    double const leaving = it.u0;
-                    double incoming = dpp_row_shl1(leaving);
-                    if (ui == nb - 1) incoming = (it.r == row0 + 3) ? 1.0 : 0.0;
-                    if (ui == 0 && it.r >= 0 && row0 >= 0 && row0 < n) Uo[row0 * WS_MAX + it.r] = leaving;
-                    it.u0 = it.u1; it.u1 = it.u2; it.u2 = incoming;
-                }
-            }
-        }
         __syncthreads();
     }
 
     for (int idx = tid; idx < n * n; idx += CHASE_THREADS) {
         int r = idx % n, c = idx / n;
         H[(size_t)(t.lo + c) * ldH + t.lo + r] = W[c * LDW + r];
-        if (!UREG) Uo[c * WS_MAX + r] = U[c * LDW + r];
-    }
-    if (UREG) {
-        // what the items still hold (the bulges' last positions), and the identity right of the leading bulge
-        int const last = max(left, right - 1);                 // `begin` of the last step (no step: the first positions)
-        int const c0 = last + 3 * ui + 1;
-        #pragma unroll
-        for (int which = 0; which < USETS; which++) {
-            UItem const &it = uu[which];
-            if (it.r < 0) continue;
-            if (c0 >= 0 && c0 < n) Uo[c0 * WS_MAX + it.r] = it.u0;
-            if (c0 + 1 >= 0 && c0 + 1 < n) Uo[(c0 + 1) * WS_MAX + it.r] = it.u1;
-            if (c0 + 2 >= 0 && c0 + 2 < n) Uo[(c0 + 2) * WS_MAX + it.r] = it.u2;
-        }
-        int const cfirst = max(0, last + 3 * nb + 1);          // first column no bulge has reached
-        for (int idx = tid; idx < (n - cfirst) * n; idx += CHASE_THREADS) {
-            int const r = idx % n, c = cfirst + idx / n;
-            Uo[c * WS_MAX + r] = (r == c) ? 1.0 : 0.0;
-        }
+        Uo[c * WS_MAX + r] = U[c * LDW + r];
     }
 }
 
-__global__ __launch_bounds__(CHASE_THREADS)
-void schur_chase_kernel(SweepStep const step, double *__restrict__ H, int ldH,
-    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
-{
-    __builtin_amdgcn_s_setprio(3);      // the latency-bound chain outranks the update kernels in instruction issue
-    schur_chase_body<0, true>(step, H, ldH, Uout, sr, si);
-}
-// 512 threads, at most 128 VGPRs: two waves per SIMD, so that the workgroup fits beside one update workgroup in
-// registers as well (update kernels: ~200 VGPRs, one wave per SIMD and workgroup) -- SN_SCHUR_CHASE_THREADS=512
-__global__ __launch_bounds__(512, 4)
-void schur_chase_512_kernel(SweepStep const step, double *__restrict__ H, int ldH,
-    double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
-{
-    __builtin_amdgcn_s_setprio(3);
-    schur_chase_body<0, true, 512>(step, H, ldH, Uout, sr, si);
-}
-// rounds 1-4 and the default: the accumulated factor in LDS beside the window
+// the window AND the accumulated factor in LDS (150 KB): one workgroup per chain
 __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_ulds_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
-    __builtin_amdgcn_s_setprio(3);
-    schur_chase_body<0, false>(step, H, ldH, Uout, sr, si);
+    __builtin_amdgcn_s_setprio(3);      // the latency-bound chain outranks the update kernels in instruction issue
+    schur_chase_body<0>(step, H, ldH, Uout, sr, si);
 }
 #ifdef SN_TEST_HOOKS
 template <int DBG>
@@ -369,7 +262,7 @@ __global__ __launch_bounds__(CHASE_THREADS)
 void schur_chase_dbg_kernel(SweepStep const step, double *__restrict__ H, int ldH,
     double *__restrict__ Uout, double const *__restrict__ sr, double const *__restrict__ si)
 {
-    schur_chase_body<DBG, false>(step, H, ldH, Uout, sr, si);
+    schur_chase_body<DBG>(step, H, ldH, Uout, sr, si);
 }
 #endif
 
@@ -584,12 +477,8 @@ struct SchurWorkspace {
         SN_HIP_CHECK(hipHostMalloc((void **)&hSub, (size_t)n * 8, hipHostMallocDefault));
         SN_HIP_CHECK(hipHostMalloc((void **)&hShift, (size_t)4 * 8 * nwmax * 8, hipHostMallocDefault));
         if (!attr_set) {
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
-                hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_ulds_kernel,
                 hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES_WU));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_512_kernel,
-                hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
             int lo_prio = 0, hi_prio = 0;
             SN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
             make_stream(&far, true, hi_prio);
@@ -882,7 +771,12 @@ struct Driver {
         set_matrix(ts, nw, nw, 0.0, 1.0, L.dZ, ld);
         // (1) Schur form of the window, recursively on the device
         std::vector<double> wr(nw), wi(nw);
-        int const rc1 = schur_device(ts, nw, L.dT, ld, L.dZ, ld, wr.data(), wi.data(), SchurParams{}, nullptr, -1, 1);
+        // (the sub-problem inherits the parent's resolved deflation threshold -- u ||H||_F of the WHOLE matrix, the
+        // value the deflation checks below use on the same window -- as the reference's does, schur/core.c:1525;
+        // 0 stands for the LAPACK criterion)
+        SchurParams p1;
+        p1.threshold = thres > 0.0 ? thres : -3.0;
+        int const rc1 = schur_device(ts, nw, L.dT, ld, L.dZ, ld, wr.data(), wi.data(), p1, nullptr, -1, 1);
         SN_HIP_CHECK(hipStreamSynchronize(ts));
         double const tl1 = wall(); prof_laed[0] += tl1 - tl0;
         if (rc1 != STARNEIG_SUCCESS) {          // no usable Schur form: report the shifts we have, deflate nothing
@@ -1172,20 +1066,7 @@ struct Driver {
             // chain's first window would race with the finished chain's pending updates
             // (tests/test_schur_pipeline.py checks this rule on a model of the schedule).
             if (sw.issued > 0 && sw.last_t != t - 1) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.far_done[evp], 0));
-            // Default: the kernel of rounds 1-4 (window AND accumulated factor in LDS, 150 KB, 96 VGPRs).  Round 5
-            // built what round 4's anatomy asked for -- the factor out of LDS (registers + DPP hand-off, 75 KB) --
-            // and measured: alone 101 us against 98 us; a workgroup with 1024 threads then still cannot share a CU
-            // with an update workgroup because of REGISTERS (4 waves x 112 VGPRs per SIMD + 208 of the update
-            // kernel > 512), the 512-thread variant can (2 x 128 + 208) and takes 122 us alone; in situ the Schur leg
-            // is 1.67-1.72 s with all three (profiles/r5_chase_variants.txt).  SN_SCHUR_CHASE_UREG=1 [SN_SCHUR_CHASE_THREADS=512].
-            if (tuning().schur_chase_ureg && tuning().schur_chase_threads == 512)
-                hipLaunchKernelGGL(schur_chase_512_kernel, dim3(ntasks), dim3(512), CHASE_LDS_BYTES, s,
-                    step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
-            else if (!tuning().schur_chase_ureg)
-                hipLaunchKernelGGL(schur_chase_ulds_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES_WU, s,
-                    step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
-            else
-            hipLaunchKernelGGL(schur_chase_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES, s,
+            hipLaunchKernelGGL(schur_chase_ulds_kernel, dim3(ntasks), dim3(CHASE_THREADS), CHASE_LDS_BYTES_WU, s,
                 step, H, ldH, Ubuf, ws.dShiftR, ws.dShiftI);
             sweep_launches++;
             int min_lo = n, max_lo = 0;
@@ -1598,7 +1479,7 @@ int schur_device(hipStream_t caller, int n, double *dH, int ldH, double *dQ, int
 
 #ifdef SN_TEST_HOOKS   // compiled into libstarneig_amd_test.so only (csrc/Makefile), never into the product library
 // ---- measurement hook (NOT part of the public C-ABI; scratch/chase_bench.py): average duration
-// of one schur_chase_kernel launch with `chains` full windows on a random Hessenberg matrix
+// of one schur_chase_ulds_kernel launch with `chains` full windows on a random Hessenberg matrix
 extern "C" __attribute__((visibility("default")))
 double sn_internal_chase_bench(int chains, int reps, int dbg)
 {
@@ -1620,8 +1501,6 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
     for (size_t k = 0; k < shr.size(); k++) shr[k] = 0.1 + 0.01 * k;
     SN_HIP_CHECK(hipMemcpy(sr, shr.data(), shr.size() * 8, hipMemcpyHostToDevice));
     SN_HIP_CHECK(hipMemcpy(si, shi.data(), shi.size() * 8, hipMemcpyHostToDevice));
-    SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_kernel,
-        hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
     int const size = n, spc = divceil(size - ws_, adv) + 1;
     SweepStep step{0, n, ws_, nbc, adv, gap, nbc * chains, spc, 0, 0, 0};
     step.t = gap * (chains - 1) + 2; step.cmin = 0; step.ntasks = chains;     // every chain mid-flight
@@ -1640,10 +1519,7 @@ double sn_internal_chase_bench(int chains, int reps, int dbg)
             case 3: go(schur_chase_dbg_kernel<3>); break;
             case 4: go(schur_chase_dbg_kernel<4>); break;
             case 7: go(schur_chase_dbg_kernel<7>); break;
-            case 8: go(schur_chase_ulds_kernel); break;
-            case 9: SN_HIP_CHECK(hipFuncSetAttribute((const void *)schur_chase_512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHASE_LDS_BYTES));
-                    hipLaunchKernelGGL(schur_chase_512_kernel, dim3(chains), dim3(512), CHASE_LDS_BYTES, nullptr, step, H, ld, U, sr, si); break;
-            default: go(schur_chase_kernel);
+            default: go(schur_chase_ulds_kernel);
         }
         SN_HIP_CHECK(hipEventRecord(e1, nullptr));
         SN_HIP_CHECK(hipEventSynchronize(e1));

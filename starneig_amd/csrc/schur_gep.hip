@@ -609,7 +609,7 @@ struct GepDriver {
     }
 
     double prof_laed[4] = {0, 0, 0, 0}; int prof_laed_calls = 0, prof_laed_windows = 0;
-    host::AedResult large_aed(int kw, int nw, double sub, double thres, SchurParams const &prm,
+    host::AedResult large_aed(int kw, int nw, double sub, double thres, double thres_inf, SchurParams const &prm,
         double *spike, double *sr, double *si)
     {
         host::AedResult res{0, 0, 0};
@@ -625,8 +625,15 @@ struct GepDriver {
         set_matrix(s, nw, nw, 0.0, 1.0, L.dZ, ld);
         // (1) generalized Schur form of the window, recursively on the device (default small AED windows)
         std::vector<double> war(nw), wai(nw), wbe(nw);
+        // The sub-problem INHERITS the thresholds the parent resolved from the whole pencil (the reference builds it
+        // with starneig_build_process_args_from, schur/core.c:1525 / :2426-2460): positive values are taken as given
+        // by the recursive call, so u ||A||_F, u ||B||_F are not recomputed from the window (they would come out
+        // smaller than the `thres` the deflation checks below apply to the same window).  0 stands for the LAPACK
+        // criteria, which are per entry / per window by definition.
         SchurParams p1;
-        p1.threshold = prm.threshold; p1.threshold_b = prm.threshold_b; p1.threshold_inf = prm.threshold_inf;
+        p1.threshold = thres > 0.0 ? thres : -3.0;
+        p1.threshold_inf = thres_inf;
+        p1.threshold_b = thres_b > 0.0 ? thres_b : prm.threshold_b;
         p1.host_threads = prm.host_threads;
         int const rc1 = gep_schur_device(s, nw, L.dA, ld, L.dB, ld, L.dQ, ld, L.dZ, ld, war.data(), wai.data(), wbe.data(),
             p1, nullptr, 1);
@@ -995,7 +1002,7 @@ int gep_schur_device(hipStream_t caller, int n, double *dA, int ldA, double *dB,
         bool const blocked = level == 0 && nw > hard_limit && nw >= 2 * GWS;
         host::AedResult ar;
         double t_aed0 = wall();
-        if (blocked) ar = d.large_aed(kw, nw, sub, thres, prm, spike.data(), sr.data(), si.data());
+        if (blocked) ar = d.large_aed(kw, nw, sub, thres, thres_inf, prm, spike.data(), sr.data(), si.data());
         else {
             d.download_windows(kw, nw);
             t_aed0 = wall();

@@ -13,18 +13,17 @@ struct Tuning {
     long hess_cache_mb = 256;       // SN_HESS_CACHE_MB: trailing matrices below this size are read with temporal loads
     int hess_side_cus = 0;          // SN_HESS_SIDE_CUS: CU mask of the side stream (0 = none)
     bool hess_noside = false;       // SN_HESS_NOSIDE: delayed updates on the critical stream
-    int hess_fold = 0;              // SN_HESS_FOLD: fold of the sharded gemv's partials (0 release/acquire ticket, 1 sc1 only, 2 own launch)
+    int hess_fold = 0;              // SN_HESS_FOLD: fold of the sharded gemv's partials (0 in the launch, behind a release / acquire ticket; 2 a launch of its own)
     bool team_pooled_stream = false;// SN_TEAM_POOLED_STREAM: the ranks' streams plain (pooled hardware queues) as in round 4 (reproducer)
     bool team_verify = false;       // SN_TEAM_VERIFY: hash every in-process collective's result on every rank and compare
-    int team_fail_rank = -1;        // SN_TEAM_FAIL_RANK: this rank of the one-process team reports "no memory" (tests of the error path)
+    int team_fail_rank = -1;        // SN_TEAM_FAIL_RANK: this rank of the one-process team reports "no memory" (tests of the error path);
+                                    // -2: the rank is read from SN_TEAM_FAIL_RANK_NOW at every reduction (a failure BETWEEN two successes)
     // Schur
     bool schur_nolazyrows = false;  // SN_SCHUR_NOLAZYROWS
     int schur_lazy_batch = 32;      // SN_SCHUR_LAZY_BATCH
     int schur_helpers = -1;         // SN_SCHUR_HELPERS: helper threads of the host window kernels (0 = none, -1 = five if the node has the cores)
     int schur_reuse = 0;            // SN_SCHUR_REUSE: fixed shift multiplicity (0 = adaptive)
     bool schur_nolookahead = false; // SN_SCHUR_NOLOOKAHEAD
-    bool schur_chase_ureg = false;  // SN_SCHUR_CHASE_UREG: the chase kernel with the accumulated factor in registers (75 KB of LDS per window)
-    int schur_chase_threads = 1024; // SN_SCHUR_CHASE_THREADS: with UREG, 512 = half the waves and <= 128 VGPRs (fits beside an update workgroup)
     bool schur_profile = false;     // SN_SCHUR_PROFILE: one line of host-side timings per reduction on stderr
     bool aed_profile = false;       // SN_AED_PROFILE
     bool schur_hs_prio = true;      // SN_SCHUR_HS_PRIO=0: lazy H stream at the priority of the lazy Q stream (else one level above)
@@ -42,7 +41,6 @@ struct Tuning {
     int ht_two_stage = -1;          // SN_HT_TWOSTAGE: the two-stage Householder path of the Hessenberg-triangular reduction (ht_twostage.hip):
                                     // 1 always, 0 never, unset: from n = ht2_min_n on
     int ht2_min_n = 1500;           // SN_HT2_MIN_N: (the rotation path is the faster one up to n ~ 1000)
-    int ht2_chains = 1;             // SN_HT2_CHAINS: streams the sweeps of its stage 2 are dealt to (1 .. 4; more than one is slower)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 0;              // SN_GEP_REUSE

@@ -22,7 +22,7 @@ Tuning const &tuning()
         t.hess_max_panels = geti("SN_HESS_MAX_PANELS", t.hess_max_panels);
         t.hess_cache_mb = geti("SN_HESS_CACHE_MB", (int)t.hess_cache_mb);
         t.hess_noside = getb("SN_HESS_NOSIDE");
-        t.hess_fold = geti("SN_HESS_FOLD", t.hess_fold);
+        t.hess_fold = geti("SN_HESS_FOLD", t.hess_fold) == 2 ? 2 : 0;
         t.team_fail_rank = geti("SN_TEAM_FAIL_RANK", t.team_fail_rank);
         t.team_verify = getb("SN_TEAM_VERIFY");
         t.team_pooled_stream = getb("SN_TEAM_POOLED_STREAM");
@@ -32,8 +32,6 @@ Tuning const &tuning()
         t.schur_helpers = geti("SN_SCHUR_HELPERS", t.schur_helpers);
         t.schur_reuse = std::max(0, std::min(8, geti("SN_SCHUR_REUSE", 0)));
         t.schur_nolookahead = getb("SN_SCHUR_NOLOOKAHEAD");
-        t.schur_chase_ureg = getb("SN_SCHUR_CHASE_UREG");
-        t.schur_chase_threads = geti("SN_SCHUR_CHASE_THREADS", t.schur_chase_threads);
         t.schur_profile = getb("SN_SCHUR_PROFILE");
         t.aed_profile = getb("SN_AED_PROFILE");
         t.schur_cumask = geti("SN_SCHUR_CUMASK", t.schur_cumask);
@@ -48,7 +46,6 @@ Tuning const &tuning()
         t.gemm_separate_sum = geti("SN_GEMM_SEPSUM", 1) != 0;
         t.ht_two_stage = geti("SN_HT_TWOSTAGE", t.ht_two_stage);
         t.ht2_min_n = geti("SN_HT2_MIN_N", t.ht2_min_n);
-        t.ht2_chains = std::max(1, std::min(4, geti("SN_HT2_CHAINS", t.ht2_chains)));
         t.gep_serial = getb("SN_GEP_SERIAL");
         t.gep_reuse = std::max(0, std::min(8, geti("SN_GEP_REUSE", 0)));
         t.gep_window = geti("SN_GEP_WINDOW", t.gep_window);

@@ -231,3 +231,25 @@ def test_problem_larger_than_the_device_is_an_error_code_not_an_abort(node):
     A = A0.copy(order="F"); Q = O.identity(m)
     assert node.SEP_SM_Hessenberg(m, A, A.shape[0], Q, Q.shape[0]) == 0
     assert O.residual_u(Q, A, A0) < 50
+
+
+@pytest.mark.parametrize("n,ld,partial", [(2000, None, False), (777, 781, False), (3000, None, True)])
+def test_two_reductions_of_one_matrix_give_the_same_bits(node, n, ld, partial):
+    """the Hessenberg reduction is bit-reproducible.  The cross-workgroup sums of the
+    column chain (w, w_v, the norm) are added up in workgroup order by the last workgroup of a slot
+    (csrc/hessenberg.hip slot_fold), the slices of the split-K products in slice order
+    (csrc/dgemm_mfma.hip dgemm_splitk_sum_kernel); rounds 1-5 used fp64 atomics for both -- the reference's
+    STARPU_COMMUTE accumulations, hessenberg/tasks.c:374,515,622 -- and two runs differed in the last bits.
+    Aligned and odd leading dimension (the 8-byte gemv), a partial range, three runs each; the matrices of other
+    sizes in between make the cached workspaces hold stale data of another shape."""
+    A0 = O.random_fullpos(n, ld=ld)
+    out = []
+    for rep in range(3):
+        if partial:
+            A, Q = run_host_api(node, partial_input(n, 100, n - 50), 100, n - 50)
+        else:
+            A, Q = run_host_api(node, A0)
+        out.append((A, Q))
+        run_host_api(node, O.random_fullpos(300 + 211 * rep, seed=7 + rep))
+    for A, Q in out[1:]:
+        assert np.array_equal(A, out[0][0]) and np.array_equal(Q, out[0][1])

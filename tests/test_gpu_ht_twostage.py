@@ -116,3 +116,88 @@ def test_two_stage_reduction_is_a_correct_hessenberg_triangular_reduction():
     env = dict(os.environ, STARNEIG_AMD_TUNING="1", SN_HT_TWOSTAGE="1")
     p = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0 and "OK" in p.stdout, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
+
+
+GENERAL = r"""
+import os, sys
+import numpy as np
+import torch
+torch.cuda.set_device(0); torch.zeros(1, device="cuda")
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import starneig_amd as S
+import oracle as O
+from helpers import to_device, to_host, torch_check_pencil
+S.node_init(8, 1, S.NO_MESSAGES)
+want_two_stage = sys.argv[1] == "1"
+u = 2.0 ** -52
+# ---- general pencil, n = 2000: (H, T) and the eigenvalues against LAPACK's (tests/golden/make_golden_gep_general.py)
+gold = np.load(os.path.join("tests", "golden", "gep_general_lcg2019_n2000.npz"))
+n = int(gold["n"])
+A0, B0 = O.random_fullpos_pair(n)
+assert np.array_equal(A0[:n, 0], gold["a_col0"]) and np.array_equal(A0[:n, -1], gold["a_last_col"])
+assert np.array_equal(B0[:n, 0], gold["b_col0"]) and np.array_equal(B0[:n, -1], gold["b_last_col"])
+tA, tB = to_device(A0), to_device(B0)
+tQ, tZ = to_device(O.identity(n)), to_device(O.identity(n))
+rc, st = S.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
+assert rc == 0 and bool(st["two_stage"]) == want_two_stage, (rc, st)
+H, T = to_host(tA), to_host(tB)
+assert O.count_below_subdiagonal(H) == 0 and O.count_below_diagonal(T) == 0
+# invariants BOTH paths must share with the input: T = Q^T B Z has B's singular values, H = Q^T A Z has A's
+# Frobenius norm (LAPACK's numbers in the fixture)
+sv = np.linalg.svd(T[:n], compute_uv=False)
+sv_err = np.abs(sv - gold["b_singular_values"]).max() / gold["b_singular_values"][0] / u
+assert sv_err < 200.0, sv_err
+assert abs(np.linalg.norm(H[:n]) - float(gold["a_fro"])) <= 100 * u * float(gold["a_fro"])
+ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
+rb, _, _ = torch_check_pencil(tQ, tB, tZ, to_device(B0), n)
+assert max(ra, rb, oq, oz) < 500.0, (ra, rb, oq, oz)
+rc, ar, ai, be, st2 = S.gep_schur_device(tA, tB, tQ, tZ, n=n)
+assert rc == 0 and O.check_gep_schur_form(to_host(tA), to_host(tB)) == 0
+ra, oq, oz = torch_check_pencil(tQ, tA, tZ, to_device(A0), n)
+rb, _, _ = torch_check_pencil(tQ, tB, tZ, to_device(B0), n)
+assert max(ra, rb, oq, oz) < 500.0, (ra, rb, oq, oz)
+tol = max(1e4, 20.0 * float(gold["lapack_spread_u"]), 50.0 * float(gold["sens_u_per_u"]))
+assert np.all(be != 0.0)
+eig = O.match_eigenvalues((ar + 1j * ai) / be, gold["eig_real"] + 1j * gold["eig_imag"])
+print(f"n={n} two_stage={want_two_stage}: singular values of T vs LAPACK's of B {sv_err:.1f} u, residuals {ra:.0f} / {rb:.0f} u, "
+      f"eigenvalues vs LAPACK {eig:.0f} u (tolerance {tol:.0f} u)", flush=True)
+assert eig < tol, (eig, tol)
+# ---- rank-deficient B, n = 1600 (three zero rows): the chain through the plain interface, the infinite eigenvalues
+gold = np.load(os.path.join("tests", "golden", "gep_general_lcg2019_n1600.npz"))
+n = int(gold["n"])
+A0, B0 = O.random_fullpos_pair(n)
+for r in gold["zero_rows"]:
+    B0[int(r), :] = 0.0
+assert np.array_equal(A0[:n, 0], gold["a_col0"]) and np.array_equal(B0[:n, -1], gold["b_last_col"])
+ld = A0.shape[0]
+A, B = A0.copy(order="F"), B0.copy(order="F")
+Q, Z = O.identity(n, ld=ld), O.identity(n, ld=ld)
+ar, ai, be = np.zeros(n), np.zeros(n), np.zeros(n)
+assert S.GEP_SM_Reduce(n, A, ld, B, ld, Q, ld, Z, ld, ar, ai, be) == 0
+assert O.check_gep_schur_form(A, B) == 0
+ninf = int((be == 0.0).sum())
+assert ninf == int(gold["n_infinite"]) == 3, ninf
+fin = be != 0.0
+ev = (ar[fin] + 1j * ai[fin]) / be[fin]
+ref = gold["eig_real"] + 1j * gold["eig_imag"]
+eig = O.match_eigenvalues(ev, ref)
+ra = O.pencil_residual_u(Q, A, Z, A0); rb = O.pencil_residual_u(Q, B, Z, B0)
+print(f"n={n} singular B: {ninf} infinite eigenvalues (LAPACK: {int(gold['n_infinite'])}), finite ones vs LAPACK {eig:.0f} u, residuals {ra:.0f} / {rb:.0f} u", flush=True)
+assert eig < 1e6 and max(ra, rb) < 500.0, (eig, ra, rb)
+S.node_finalize()
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("two_stage", [1, 0])
+def test_reduce_of_a_general_pencil_against_lapack(two_stage):
+    """the two-stage path (the default from n = 1500) against the oracle's pins on a GENERAL
+    pencil -- n = 2000, the test driver's generalized Hessenberg input: singular values of T against LAPACK's of B,
+    Hessenberg-triangular + QZ eigenvalues against LAPACK dggev's (committed fixture, tolerance from LAPACK's own
+    spread and the measured sensitivity), and a rank-deficient B at n = 1600 through starneig_GEP_SM_Reduce: the count
+    of beta = 0 must be LAPACK's.  Run on the two-stage path and -- same assertions, the invariants both must share
+    -- on the rotation path (SN_HT_TWOSTAGE, read once per process: child processes).  The reference's hooks for this
+    chain: test/common/hooks.c:787-991."""
+    env = dict(os.environ, STARNEIG_AMD_TUNING="1", SN_HT_TWOSTAGE=str(two_stage))
+    p = subprocess.run([sys.executable, "-c", GENERAL, str(two_stage)], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])

@@ -65,3 +65,39 @@ def test_stage_2_in_wavefronts_of_lag_2(n, r, singular):
     assert la3 == 0.0 and ra3 <= 100 * U and w2 < 0.75 * w3
     _, _, _, ra1, _ = run(1)
     assert ra1 > 1e6 * U
+
+
+# ---- which applications of stage 2 may be deferred (round 6) ---------------------------------------------------------
+spec3 = importlib.util.spec_from_file_location("ht2_defer", os.path.join(ROOT, "scratch", "ht2_defer.py"))
+D = importlib.util.module_from_spec(spec3)
+spec3.loader.exec_module(D)
+
+
+@pytest.mark.parametrize("n,r,gs,singular", [(97, 8, 8, True), (150, 8, 16, False), (200, 16, 64, False)])
+def test_stage_2_with_the_top_rows_of_the_right_reflectors_deferred(n, r, gs, singular):
+    """csrc/ht_twostage.hip applies the opposite reflector of sweep j at once only to the rows from
+    top = (j // GS) GS + 1 on; the rows above take the reflectors of a whole group later, position by position in
+    decreasing order (beside Z).  Valid because those rows see no left reflector from the group's first wavefront on
+    (scratch/ht2_defer.py has the argument).  The same deferral of the LEFT reflectors' far columns must NOT work --
+    a later right reflector that straddles the boundary mixes updated and stale columns -- or this test checks
+    nothing: it is the reason the left application stays in the chase."""
+    def run(mode):
+        rng = np.random.default_rng(n)
+        A0 = rng.standard_normal((n, n)); B0 = np.triu(rng.standard_normal((n, n)))
+        if singular:
+            B0[10, 10] = 0.0; B0[50, 50] = 0.0
+        A, B = A0.copy(), B0.copy(); Q = np.eye(n); Z = np.eye(n)
+        P.stage1(A, B, Q, Z, r)
+        cnt = {"now": 0, "later": 0}
+        D.stage2_deferred(A, B, Q, Z, r, gs, mode, count=cnt)
+        return (np.abs(np.tril(A, -2)).max(), np.abs(np.tril(B, -1)).max(),
+                np.linalg.norm(Q @ A @ Z.T - A0) / np.linalg.norm(A0) / U,
+                np.linalg.norm(Q @ B @ Z.T - B0) / np.linalg.norm(B0) / U, cnt)
+    la0, lb0, ra0, rb0, c0 = run("none")
+    la, lb, ra, rb, c1 = run("right_top")
+    assert la == 0.0 and lb == 0.0 and ra < 100 and rb < 100, (la, lb, ra, rb)
+    assert abs(ra - ra0) < 5 and abs(rb - rb0) < 5
+    # a quarter of the chase's bytes leave it (half of the right application's), what comes back is blocked
+    assert c1["now"] < 0.85 * c0["now"] and c1["later"] < 0.15 * c0["now"]
+    la, lb, ra, rb, _ = run("left_far")
+    assert ra > 1e6 or rb > 1e6
