@@ -98,7 +98,10 @@ def run_qz(S, n, kind, steps, warmup):
            "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
            "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
            "below_subdiagonal_nonzeros": ca["below_subdiagonal"],
-           "qz_sweeps": st["sweeps"], "aeds": st["aeds"], "aed_host_s": st["aed_host_s"]}
+           "qz_sweeps": st["sweeps"], "aeds": st["aeds"], "aed_host_s": st["aed_host_s"],
+           # SURVEY 8d for a latency-bound leg: no roofline, the share of the time on the dependent chain of host
+           # window kernels (one AED window after the other; the GPU's sweeps and updates fill the rest)
+           "bound": "latency: the host's chain of AED windows", "critical_path_frac": st["aed_host_s"] / (total / steps)}
     del tH0, tR0, tQ, tZ
     torch.cuda.empty_cache()
     return out
@@ -133,6 +136,8 @@ def run_gep_chain(S, n):
                "hessenberg_triangular_path": "two-stage Householder" if st.get("two_stage") else "rotations",
                "ns_per_chain_rotation": None if st.get("two_stage") else st["rotation_ms"] * 1e6 / max(st["rotations"] / 2, 1),
                "qz_sweeps": st2["sweeps"], "aeds": st2["aeds"], "aed_host_s": st2["aed_host_s"],
+               "qz_bound": "latency: the host's chain of AED windows", "qz_critical_path_frac": st2["aed_host_s"] / max(t2 - t1, 1e-9),
+               "hessenberg_triangular_stage1_s": st.get("stage1_ms", 0.0) / 1e3,
                "qz_executed_gemm_tflop": st2["gemm_flops"] / 1e12,
                "residual_a_u": ca["residual_u"], "residual_b_u": cb["residual_u"],
                "orthogonality_q_u": ca["orthogonality_q_u"], "orthogonality_z_u": ca["orthogonality_z_u"],
@@ -192,14 +197,17 @@ def lapack_ht_seconds(n):
         return None
 
 
-def two_stage_roofline(n, st):
+def two_stage_roofline(n, st, traffic=None):
     """Stage 2 of the two-stage path (csrc/ht_twostage.hip) streams A and B through the reflector applications
-    of its n^2 / 128 steps: rows p:p1 of A (columns right of the bulge) and B (columns p:n) from the left, columns
-    p:p1 of A (rows 0:p1+64) and B (rows 0:p1) from the right, 16 bytes an entry (read + write).  Algorithmic bytes
-    of those kernels over the whole of stage 2 (reflector generation, 75 us of latency a wavefront, included in the
-    time) against the HBM peak."""
+    of its n^2 / 128 steps: rows p:p1 of A (columns right of the bulge) and B (columns p:n) from the left; columns
+    p:p1 of A (rows top:p1+64) and B (rows top:p1) from the right, top = (j // 64) * 64 + 1 -- the rows above take
+    the opposite reflectors of a whole group of 64 sweeps later, as compact-WY blocks (round 6; one pass over
+    rows 0:top of the 127 columns of a block per group and position).  16 bytes an entry (read + write).
+    Algorithmic bytes of those kernels over the whole of stage 2 (reflector generation, 75 us of latency a
+    wavefront, included in the time) against the HBM peak.  traffic: PMC bytes of the same kernels when a counter
+    pass is at hand (profiles/), else None."""
     import numpy as np
-    r = 64
+    r, gs = 64, 64
     j = np.arange(n - 2, dtype=np.int64)[:, None]
     t = np.arange((n - 3) // r + 1, dtype=np.int64)[None, :]
     p = j + 1 + r * t
@@ -207,14 +215,25 @@ def two_stage_roofline(n, st):
     p1 = np.minimum(p + r, n)
     ln = p1 - p
     c0 = np.where(t == 0, j, p - r)
+    top = (j // gs) * gs + 1
     left = ln * ((n - c0 - 1) + (n - p))
-    right = ln * (np.minimum(p1 + r, n) + p1)
-    nbytes = 16.0 * float(((left + right) * live).sum())
+    right = ln * ((np.minimum(p1 + r, n) - top) + (p1 - top))
+    chase = 16.0 * float(((left + right) * live).sum())
+    # the deferred rows: per group g and position t one pass over rows 0:top of <= 127 columns of A and B
+    g = np.arange((n - 2 + gs - 1) // gs, dtype=np.int64)[:, None]
+    col0 = g * gs + 1 + r * t
+    k = np.minimum(gs, n - 1 - col0)
+    m = np.minimum(k - 1 + r, n - col0)
+    later = 16.0 * float((2 * (g * gs + 1) * m * (k > 0)).sum())
+    nbytes = chase + later
     stage2_s = (st["rotation_ms"] - st["stage1_ms"]) / 1e3
     return {"bound": "hbm", "achieved": nbytes / stage2_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "frac": nbytes / stage2_s / 1e9 / 8000.0, "traffic": None,
-            "kernel": "ht2_apply_left_kernel + ht2_apply_right_kernel over stage 2 (%.2f s, %.1f TB algorithmic)"
-                      % (stage2_s, nbytes / 1e12)}
+            "frac": nbytes / stage2_s / 1e9 / 8000.0, "traffic": traffic,
+            "kernel": "ht2_geng_left_kernel (left application) + ht2_apply_right_kernel + the deferred rows in "
+                      "ht2_wy_right_kernel over stage 2 (%.2f s, %.1f TB algorithmic of which %.2f TB deferred; "
+                      "rounds 1-5 applied everything at once: %.1f TB)"
+                      % (stage2_s, nbytes / 1e12, later / 1e12,
+                         16.0 * float(((left + ln * (np.minimum(p1 + r, n) + p1)) * live).sum()) / 1e12)}
 
 
 def bench_ht(args):

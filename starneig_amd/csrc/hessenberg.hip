@@ -169,33 +169,30 @@ __device__ __forceinline__ void block_gemv_t_part(double const *__restrict__ M, 
 }
 
 // The ordered cross-workgroup sum.  Every workgroup of the launch has stored its partial vector part[b][0:len)
-// (+ an optional scalar spart[b]) with write-through stores; here it drains them, meets at its barrier, one lane
-// RELEASES at agent scope and draws a ticket of slot b % NSLOT; the workgroup that draws the slot's LAST ticket
-// ACQUIRES and adds the slot's partials up in workgroup order b = slot, slot + NSLOT, ... -- eight loads in flight,
-// a fixed tree -- into sum[slot][0:len) (and ssum[slot]), then resets the counter.  (cdna_hip_programming.md
-// section 6, Guideline 16, counter form -- the hand-over of the sharded gemv's fold.)  The NEXT launch reads the
-// slot sums; a slot's value never depends on which workgroup came last.
+// (+ an optional scalar spart[b]) WRITE-THROUGH (sc1: part_store); here every storing wave drains its stores, the
+// workgroup meets at its barrier and one lane draws a ticket of slot b % NSLOT (relaxed, agent scope); the workgroup
+// that draws the slot's LAST ticket adds the slot's partials up in workgroup order b = slot, slot + NSLOT, ... --
+// EVERY load of a handed-off word an sc1 load, eight in flight, a fixed tree -- into sum[slot][0:len) (and
+// ssum[slot]) and resets the counter.  (cdna_hip_programming.md section 6, Guideline 16, the counter form with
+// write-through payload: no release fence on the producers, no acquire on the reducer -- with both fences in,
+// the two column kernels took 3.7 us longer each, 0.15 s of a reduction at n = 20000; profiles/r6_column_chain.txt.)
+// The NEXT launch reads the slot sums; a slot's value never depends on which workgroup came last.
 template <int THREADS>
 __device__ __forceinline__ void slot_fold(int nwg, int len, double const *__restrict__ part, double *__restrict__ sum,
     double const *__restrict__ spart, double *__restrict__ ssum, int *__restrict__ cnt)
 {
     __shared__ int s_last;
     int const b = blockIdx.x, slot = b % NSLOT, members = (nwg - slot + NSLOT - 1) / NSLOT;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores are out
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int const last = __hip_atomic_fetch_add(cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (last) __hip_atomic_store(cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: the loads below stay below the ticket)
     auto ordered = [&](double const *p, size_t stride) {
         // member q of the slot goes to accumulator q % 8 (clamped loads, zeros beyond the last member: static
         // register indices), the eight accumulators meet in a fixed tree
@@ -438,7 +435,7 @@ void hess_gemv_kernel(double const *__restrict__ A, int ldA,
     int nshadow, int row_tiles,
     double *__restrict__ ypart, double *__restrict__ V, double *__restrict__ VT,
     double const *__restrict__ Y, double *__restrict__ t12,
-    double *__restrict__ acc, double *__restrict__ scal, int world, int rank,
+    double const *__restrict__ acc, double *__restrict__ scal, int world, int rank,
     double *__restrict__ ysum = nullptr, int *__restrict__ tile_cnt = nullptr,
     HessExchange x = HessExchange{}, int seq = 0)
 {
