@@ -354,7 +354,7 @@ void hess_finish_kernel(int R0, int E, int j /* = nb */, int ldp,
     }
 }
 
-// colC(j): p'' = p' - V(:,0:j) w ; norm^2 below the pivot ; V^T p''(piv+1:)
+// colC(j): p'' = p' - V(:,0:j) w ; norm^2 below the pivot ; V^T p''
 __global__ __launch_bounds__(CTC)
 void hess_colC_kernel(int R0, int E, int j, int ldp,
     double *__restrict__ P, double const *__restrict__ V, double *__restrict__ acc,
@@ -815,10 +815,12 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             if (j > 0)
                 hipLaunchKernelGGL(hess_colA_kernel, dim3(nwg), dim3(CT), 0, s,
                     R0, E, j, ldp, ws.P, VT, Y, ws.ypart, nsplit, ws.t12, ws.acc, ws.scal, ws.part, ws.slot_cnt);
-            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
-                R0, E, j, ldp, ws.P, V, ws.acc, ws.part, ws.npart, ws.slot_cnt + NSLOT);
             int const ncols = E - piv;
             choose_split(m, ncols, &nsplit, &cps);
+            long const cache_bytes = tuning().hess_cache_mb << 20;
+            bool const streaming = aligned && (long)m * ncols * 8 > cache_bytes;
+            hipLaunchKernelGGL(hess_colC_kernel, dim3(nwg), dim3(CTC), 0, s,
+                R0, E, j, ldp, ws.P, V, ws.acc, ws.part, ws.npart, ws.slot_cnt + NSLOT);
             bool const sampled = sample_every > 0 && (gemv_launches % sample_every) == 0;
             if (sampled) {
                 if (ws.sample_ev.size() < 2 * (nsampled + 1)) {
@@ -835,8 +837,7 @@ int hessenberg_device(hipStream_t caller, int n, int begin, int end, int panel_w
             // once the trailing matrix fits the 256 MB Infinity Cache the next column re-reads part of
             // it from there: temporal loads (the streaming, non-temporal ones bypass the caches).
             // Measured: 4 % on the whole reduction at n = 6000, nothing at n = 20000.
-            long const cache_bytes = tuning().hess_cache_mb << 20;
-            if (aligned && (long)m * ncols * 8 <= cache_bytes)
+            if (aligned && !streaming)
                 hipLaunchKernelGGL((hess_gemv_kernel<16, true, false>), grid, dim3(256), 0, s,
                     dA, ldA, ws.P, R0, E, j, cps, ldp, nshadow, row_tiles, ws.ypart, V, VT, Y, ws.t12, ws.acc, ws.scal, 1, -1);
             else if (aligned)
