@@ -787,6 +787,8 @@ __global__ void ht_clear_lower_kernel(int n, double *__restrict__ B, int ldb)
 struct HtWorkspace {
     int n = 0, ldp = 0;
     double *Vp = nullptr, *VT = nullptr, *W = nullptr, *G = nullptr, *T = nullptr, *tau = nullptr;
+    double *Vp1 = nullptr, *VT1 = nullptr, *Wside = nullptr;    // QR step: second set of panel factors, the side stream's product
+    hipEvent_t e_panel[2] = {nullptr, nullptr}, e_pfree[2] = {nullptr, nullptr};
     double *part[2] = {nullptr, nullptr}, *prow[2] = {nullptr, nullptr};
     double *Rc2[2] = {nullptr, nullptr}, *Rs2[2] = {nullptr, nullptr}, *Rc = nullptr, *Rs = nullptr;
     double *Cc2[3] = {nullptr, nullptr, nullptr}, *Cs2[3] = {nullptr, nullptr, nullptr}, *Cc = nullptr, *Cs = nullptr;
@@ -807,6 +809,8 @@ struct HtWorkspace {
             make_stream(&side, false, lo);
             make_stream(&qstream, false, lo);
             for (auto &e : e_q) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &e : e_panel) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &e : e_pfree) SN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_cdone, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_scan, hipEventDisableTiming));
             SN_HIP_CHECK(hipEventCreateWithFlags(&e_side, hipEventDisableTiming));
@@ -822,6 +826,7 @@ struct HtWorkspace {
         ldp = (int)roundup(n, 16);
         auto alloc = [](double *&p, size_t count) { SN_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(double))); };
         alloc(Vp, (size_t)ldp * QNB); alloc(VT, (size_t)ldp * QNB); alloc(W, (size_t)ldp * QNB);
+        alloc(Vp1, (size_t)ldp * QNB); alloc(VT1, (size_t)ldp * QNB); alloc(Wside, (size_t)ldp * QNB);
         alloc(G, QNB * QNB); alloc(T, QNB * QNB); alloc(tau, QNB);
         for (int b = 0; b < 2; b++) { alloc(part[b], (size_t)divceil(n, QROWS) * QP); alloc(prow[b], QNB); }
         for (int b = 0; b < 2; b++) { alloc(Rc2[b], n); alloc(Rs2[b], n); }
@@ -833,7 +838,7 @@ struct HtWorkspace {
     }
     void release_buffers()
     {
-        double **all[] = {&Vp, &VT, &W, &G, &T, &tau, &part[0], &part[1], &prow[0], &prow[1], &Rc2[0], &Rc2[1], &Rs2[0], &Rs2[1], &Cc2[0], &Cc2[1], &Cc2[2], &Cs2[0], &Cs2[1], &Cs2[2],
+        double **all[] = {&Vp, &VT, &W, &Vp1, &VT1, &Wside, &G, &T, &tau, &part[0], &part[1], &prow[0], &prow[1], &Rc2[0], &Rc2[1], &Rs2[0], &Rs2[1], &Cc2[0], &Cc2[1], &Cc2[2], &Cs2[0], &Cs2[1], &Cs2[2],
             &rp_beta[0], &rp_beta[1], &rp_up[0], &rp_up[1], &rp_alpha[0], &rp_alpha[1]};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
@@ -854,32 +859,44 @@ void row_pass(hipStream_t s, HtWorkspace &ws, int which, int n, int j, int tri, 
 void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, double *dB, int ldB,
     double *dQ, int ldQ, double *flops)
 {
+    // Only the trailing columns of B feed the next panel: they stay on `s` behind the panel's column chain.  A and Q
+    // -- three quarters of the step's flops, rank-64 updates bound by HBM -- take their updates on the side stream
+    // beside the next panels' latency-bound chains, from the second of two sets of panel factors (round 6: the step
+    // 0.57 -> 0.3x s at n = 8000; everything on one stream before).
     int const ldp = ws.ldp;
-    for (int p0 = 0; p0 < n; p0 += QNB) {
-        int const nb = std::min(QNB, n - p0), m = n - p0, nwg = divceil(m, QROWS);
+    hipStream_t const q = ws.side;
+    int pc = 0;
+    for (int p0 = 0; p0 < n; p0 += QNB, pc++) {
+        int const nb = std::min(QNB, n - p0), m = n - p0, nwg = divceil(m, QROWS), b = pc & 1;
+        double *Vp = b ? ws.Vp1 : ws.Vp, *VT = b ? ws.VT1 : ws.VT;
+        if (pc >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_pfree[b], 0));     // the side stream is through with this set
         for (int jj = 0; jj <= nb; jj++)
             hipLaunchKernelGGL(ht_qr_col_kernel, dim3(nwg), dim3(QROWS), 0, s, n, p0, nb, jj, dB, ldB,
-                ws.Vp, ldp, ws.tau, ws.part[(jj + 1) & 1], ws.part[jj & 1], ws.prow[(jj + 1) & 1], ws.prow[jj & 1], nwg);
-        dgemm(s, 'T', 'N', nb, nb, m, 1.0, ws.Vp, ldp, ws.Vp, ldp, 0.0, ws.G, QNB);
+                Vp, ldp, ws.tau, ws.part[(jj + 1) & 1], ws.part[jj & 1], ws.prow[(jj + 1) & 1], ws.prow[jj & 1], nwg);
+        dgemm(s, 'T', 'N', nb, nb, m, 1.0, Vp, ldp, Vp, ldp, 0.0, ws.G, QNB);
         hipLaunchKernelGGL(ht_qr_tfactor_kernel, dim3(1), dim3(64), 0, s, nb, ws.G, ws.tau, ws.T);
-        dgemm(s, 'N', 'N', m, nb, nb, 1.0, ws.Vp, ldp, ws.T, QNB, 0.0, ws.VT, ldp);
+        dgemm(s, 'N', 'N', m, nb, nb, 1.0, Vp, ldp, ws.T, QNB, 0.0, VT, ldp);
+        SN_HIP_CHECK(hipEventRecord(ws.e_panel[b], s));
         int const nc = n - p0 - nb;
         if (nc > 0) {
             double *Bt = dB + (size_t)(p0 + nb) * ldB + p0;
-            dgemm(s, 'T', 'N', nb, nc, m, 1.0, ws.VT, ldp, Bt, ldB, 0.0, ws.W, QNB);
-            dgemm(s, 'N', 'N', m, nc, nb, -1.0, ws.Vp, ldp, ws.W, QNB, 1.0, Bt, ldB);
+            dgemm(s, 'T', 'N', nb, nc, m, 1.0, VT, ldp, Bt, ldB, 0.0, ws.W, QNB);
+            dgemm(s, 'N', 'N', m, nc, nb, -1.0, Vp, ldp, ws.W, QNB, 1.0, Bt, ldB);
             *flops += 4.0 * m * nb * nc;
         }
-        dgemm(s, 'T', 'N', nb, n, m, 1.0, ws.VT, ldp, dA + p0, ldA, 0.0, ws.W, QNB);
-        dgemm(s, 'N', 'N', m, n, nb, -1.0, ws.Vp, ldp, ws.W, QNB, 1.0, dA + p0, ldA);
+        SN_HIP_CHECK(hipStreamWaitEvent(q, ws.e_panel[b], 0));
+        dgemm(q, 'T', 'N', nb, n, m, 1.0, VT, ldp, dA + p0, ldA, 0.0, ws.Wside, QNB);
+        dgemm(q, 'N', 'N', m, n, nb, -1.0, Vp, ldp, ws.Wside, QNB, 1.0, dA + p0, ldA);
         *flops += 4.0 * m * nb * n;
         if (dQ) {
             double *Qt = dQ + (size_t)p0 * ldQ;
-            dgemm(s, 'N', 'N', n, nb, m, 1.0, Qt, ldQ, ws.VT, ldp, 0.0, ws.W, ldp);
-            dgemm(s, 'N', 'T', n, m, nb, -1.0, ws.W, ldp, ws.Vp, ldp, 1.0, Qt, ldQ);
+            dgemm(q, 'N', 'N', n, nb, m, 1.0, Qt, ldQ, VT, ldp, 0.0, ws.Wside, ldp);
+            dgemm(q, 'N', 'T', n, m, nb, -1.0, ws.Wside, ldp, Vp, ldp, 1.0, Qt, ldQ);
             *flops += 4.0 * m * nb * n;
         }
+        SN_HIP_CHECK(hipEventRecord(ws.e_pfree[b], q));
     }
+    for (int b = 0; b < 2 && b < pc; b++) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_pfree[b], 0));
 }
 
 } // namespace
