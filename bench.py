@@ -31,9 +31,9 @@ MFMA_F64_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix peak (spec; SURVEY.md secti
 
 def pmc_traffic_ratio():
     """HBM traffic / algorithmic bytes of the panel gemv from the committed PMC passes
-    (profiles/r5_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+    (profiles/r6_gemv_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if the file is missing."""
-    for name in ("r5_gemv_pmc_traffic.json", "r4_gemv_pmc_traffic.json"):
+    for name in ("r6_gemv_pmc_traffic.json", "r5_gemv_pmc_traffic.json", "r4_gemv_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["traffic_over_algorithmic"]
@@ -730,7 +730,7 @@ def main():
                 "traffic": (ratio * sb / nl) if (ratio and nl) else None,
                 "traffic_note": "avg algorithmic bytes per launch x PMC ratio "
                                 "(2*FETCH_SIZE+WRITE_SIZE)/algorithmic measured on the 624 launches of "
-                                "the first two panels at n=20000, profiles/r5_gemv_pmc_traffic.json",
+                                "the first two panels at n=20000, profiles/r6_gemv_pmc_traffic.json",
                 "launches_timed": nl,
                 "avg_launch_us": (sm / nl * 1e3) if nl else None,
                 "avg_launch_bytes": (sb / nl) if nl else None,
@@ -788,7 +788,7 @@ def main():
                 "critical_update_ms_per_step": gm / args.steps,
                 "side_stream_tflops": (gfs / (gs * 1e-3) / 1e12) if gs > 0 else None,
                 "note": "in situ, HIP events on the critical stream around every panel's launch(es); the same kernel "
-                        "alone with PMC MFMA-busy counters: profiles/r4_dgemm_mfma_utilisation.json (the kernel is unchanged since); why in situ reads "
+                        "alone with PMC MFMA-busy counters: profiles/r4_dgemm_mfma_utilisation.json, in situ over the first four panels: profiles/r6_pmc_mfma_in_situ.json (0.760 MFMA busy; the kernel is unchanged since round 4); why in situ reads "
                         "lower than alone (clock state after the HBM-bound panel): profiles/r4_gemm_phase_experiment.txt",
             }
         if world == 1 and args.host_api:
