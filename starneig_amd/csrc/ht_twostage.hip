@@ -637,16 +637,15 @@ __global__ __launch_bounds__(WY_T) void ht2_wy_left_kernel(double const *__restr
     }
 }
 
-// X (nrows x m, m <= 2 r) <- X - (X V) (V T^T)^T; blockIdx.x: slab of WY_SLAB rows, blockIdx.y: target
-__global__ __launch_bounds__(WY_T) void ht2_wy_right_kernel(double const *__restrict__ V, double const *__restrict__ VT, int m, int k,
-    WyTargets tg)
+// X (nrows x m, m <= 2 r) <- X - (X V) (V T^T)^T; blockIdx.x: slab of WY_SLAB rows
+__device__ __forceinline__ void wy_right_body(double const *__restrict__ V, double const *__restrict__ VT, int m, int k,
+    double *__restrict__ X, int ldx, int nrows)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *Vs = lds, *Xs = Vs + R2 * WY_LDV, *Ws = Xs + 2 * R2 * WY_LDR;       // Xs[c][r], Ws[kk][r]
-    int const tid = threadIdx.x, wave = tid >> 6, l = tid & 63, q = l & 15, kk = l >> 4, z = blockIdx.y;
-    int const nrows = tg.extent[z], ldx = tg.ld[z], r0 = blockIdx.x * WY_SLAB;
+    int const tid = threadIdx.x, wave = tid >> 6, l = tid & 63, q = l & 15, kk = l >> 4;
+    int const r0 = blockIdx.x * WY_SLAB;
     if (r0 >= nrows) return;
-    double *X = tg.X[z];
     int const nr = min(WY_SLAB, nrows - r0);
     double f[WY_FREG], xr[2 * R2 * WY_SLAB / WY_T];
     wy_fetch_factor(f, V, m, k);
@@ -684,6 +683,21 @@ __global__ __launch_bounds__(WY_T) void ht2_wy_right_kernel(double const *__rest
         if (r < nr && c < m) X[(size_t)c * ldx + r0 + r] = Xs[c * WY_LDR + r];
     }
 }
+// one factor, up to three targets (blockIdx.y)
+__global__ __launch_bounds__(WY_T) void ht2_wy_right_kernel(double const *__restrict__ V, double const *__restrict__ VT, int m, int k,
+    WyTargets tg)
+{
+    int const z = blockIdx.y;
+    wy_right_body(V, VT, m, k, tg.X[z], tg.ld[z], tg.extent[z]);
+}
+// two (factor, target) pairs in one launch (blockIdx.y): stage 1 applies a step's left factor to Q and its right factor
+// to Z together -- the host, not the GPU, bounds stage 1, and a launch less is a runtime call less
+struct WyJob { double const *V, *VT; int m, k; double *X; int ld, nrows; };
+__global__ __launch_bounds__(WY_T) void ht2_wy_right2_kernel(WyJob j0, WyJob j1)
+{
+    WyJob const &j = blockIdx.y == 0 ? j0 : j1;
+    wy_right_body(j.V, j.VT, j.m, j.k, j.X, j.ld, j.nrows);
+}
 
 constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
 constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
@@ -711,6 +725,7 @@ struct Ht2Workspace {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_LEFT_LDS));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_right_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_RIGHT_LDS));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_right2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_RIGHT_LDS));
             for (int k = 0; k < RING; k++) {
                 SN_HIP_CHECK(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
                 SN_HIP_CHECK(hipEventCreateWithFlags(&used[k], hipEventDisableTiming));
@@ -849,6 +864,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     hipStream_t const sp = ws.pstream;
     bool const side = sq != s;
     long lcount = 0, rcount = 0;
+    WyJob pendq{}; int pendq_slot = 0; long pendq_count = 0; bool have_pendq = false;   // a left factor waiting for its turn on Q
     constexpr int EPOCH = RING / 2;
     // consumer side: after step i of a ring; producer side: before step L of that ring
     auto epoch_record = [&](hipEvent_t *ev, long i, hipStream_t st) { if (i % EPOCH == EPOCH - 1) SN_HIP_CHECK(hipEventRecord(ev[(i / EPOCH) % 2], st)); };
@@ -860,6 +876,13 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         // the panel's columns are final once `s` is through the previous block column
         SN_HIP_CHECK(hipEventRecord(ws.column, s));
         SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.column, 0));
+        auto flush_q = [&]() {
+            if (!have_pendq) return;
+            if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0));
+            wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
+            if (side) epoch_record(ws.used, pendq_count, sq);
+            have_pendq = false;
+        };
         auto left_step = [&](int i0, int i1) {
             int const m = i1 - i0, k = nb, sl = (int)(lcount % RING);
             double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
@@ -870,9 +893,11 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             SN_HIP_CHECK(hipStreamWaitEvent(s, ws.ready[sl], 0));
             wy_left(s, V, VT, m, k, A + (size_t)(jc + nb) * lda + i0, lda, n - jc - nb, B + (size_t)i0 * ldb + i0, ldb, n - i0);
             if (Q) {
-                if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[sl], 0));
-                wy_right(sq, V, VT, m, k, Q + (size_t)i0 * ldq, ldq, n);
-                if (side) epoch_record(ws.used, lcount, sq);
+                // the application to Q waits for the right step that follows (one launch for Q and Z); a left step
+                // without one flushes it by itself (flush_q)
+                flush_q();
+                pendq = WyJob{V, VT, m, k, Q + (size_t)i0 * ldq, ldq, n};
+                pendq_slot = sl; pendq_count = lcount; have_pendq = true;
             }
             epoch_record(ws.used_s, lcount, s);
             lcount++;
@@ -886,8 +911,15 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             if (Z && side) SN_HIP_CHECK(hipEventRecord(ws.ready_r[sl], s));
             wy_right(s, V, VT, m, mb, A + (size_t)i0 * lda, lda, n, B + (size_t)i0 * ldb, ldb, i1 - mb);
             if (Z) {
+                // (ready_r is recorded on `s` behind the wait for the left factor of this step: it covers both)
                 if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[sl], 0));
-                wy_right(sq, V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n);
+                if (have_pendq && mb > 0) {
+                    hipLaunchKernelGGL(ht2_wy_right2_kernel, dim3(divceil(n, WY_SLAB), 2), dim3(WY_T), WY_RIGHT_LDS, sq,
+                        pendq, WyJob{V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n});
+                    if (side) epoch_record(ws.used, pendq_count, sq);
+                    have_pendq = false;
+                } else
+                    wy_right(sq, V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n);
                 if (side) epoch_record(ws.used_r, rcount, sq);
             }
             rcount++;
@@ -902,6 +934,11 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         if (K == 1 && n - top > 1) left_step(top, n);
         int const i1 = std::min(top + r, n);
         if (i1 - top > 1) right_step(top, i1, i1 - top);
+    }
+    if (have_pendq) {       // (the last left factor of stage 1, if no right step followed it)
+        if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0));
+        wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
+        have_pendq = false;
     }
     if (between) SN_HIP_CHECK(hipEventRecord(between, s));
     // ---- stage 2 -----------------------------------------------------------------------------------------------

@@ -58,3 +58,22 @@ def test_full_chain_c_program_runs_the_chain_on_the_gpu(tmp_path):
     out = subprocess.run([exe, "1200"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "full_chain ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_gep_chain_c_program_compiles_and_links(tmp_path):
+    import starneig_amd as S
+    S.lib.load()
+    exe, _ = _compile(tmp_path, "gep_chain.c", "gep_chain")
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_gep_chain_c_program_runs_the_generalized_chain_on_the_gpu(tmp_path):
+    """The generalized twin: starneig_GEP_SM_HessenbergTriangular + starneig_GEP_SM_Schur from a C program on host
+    arrays (examples/gep_sm_full_chain.c:55-130 without the generalized reordering, which is not built), the
+    example's checks on both matrices and both orthogonal factors (< 1000 u), the generalized Schur form entry by
+    entry."""
+    exe, env = _compile(tmp_path, "gep_chain.c", "gep_chain")
+    out = subprocess.run([exe, "900"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gep_chain ok" in out.stdout, out.stdout + out.stderr
