@@ -111,11 +111,18 @@ bool fits_device(int n, int count, char const *what)
     return false;
 }
 
-int default_panel_width(int n)          // hessenberg/interface.c:74-78
+// The panel width the library picks when the caller asks for the default (conf->panel_width =
+// STARNEIG_HESSENBERG_DEFAULT_PANEL_WIDTH; the plain interface).  The reference's own choice is
+// MAX(64, divceil((int)(0.001875596476 n + 273.59), 8) * 8) = 280 / 288 / 312 for n = 2000 / 8000 / 20000
+// (hessenberg/interface.c:74-78), a fit to ITS tile kernels.  Here the per-column chain costs a pass over the
+// panel factors that grows with the column's index in the panel, while the compact-WY updates lose little at
+// k = 128 ... 192, so narrower panels are faster at every size measured on an MI355X (round 6,
+// profiles/r6_panel_width_sweep.txt: n = 2000 0.057 -> 0.051 s, 4000 0.139 -> 0.127, 8000 0.486 -> 0.455, 12000
+// 1.223 -> 1.173, 20000 4.66 -> 4.55 s; multiples of 64 sit best with the 128-wide GEMM tiles).  A caller who
+// wants the reference's width passes it in the conf; every width from 8 up is honoured as before.
+int default_panel_width(int n)
 {
-    int a = (int)(0.001875596476 * n + 273.5908216);   // divceil(int,int), common/common.h:207
-    int w = (a + 7) / 8 * 8;
-    return std::max(64, w);
+    return n <= 16000 ? 128 : 192;
 }
 
 } // namespace

@@ -874,7 +874,7 @@ struct Driver {
             copy_matrix(ts, ns, ns, L.dT, ld, L.dP + ld + 1, ld);
             SN_HIP_CHECK(hipMemcpyAsync(L.dP + 1, sp.data(), (size_t)ns * 8, hipMemcpyHostToDevice, ts));
             SN_HIP_CHECK(hipStreamSynchronize(ts));     // sp is pageable
-            int pw = (int)(0.001875596476 * np + 273.5908216); pw = std::max(64, (pw + 7) / 8 * 8);
+            int const pw = 128;         // (the library's default panel width below n = 16000, capi.hip)
             hessenberg_device(ts, np, 0, np, pw, L.dP, ld, L.dQp, ld, nullptr);
             // U = Qp(1:,1:):  T(0:ns, ns:nw) <- U^T . ;  Z(:, 0:ns) <- . U ;  T(0:ns,0:ns) <- P(1:,1:)
             double const *U = L.dQp + ld + 1;

@@ -76,7 +76,10 @@ def test_not_initialized():
 def test_conf_defaults_and_panel_width():
     conf = S.hessenberg_init_conf()
     assert (conf.tile_size, conf.panel_width) == (-1, -1)
-    assert [S.default_panel_width(n) for n in (2000, 8000, 20000)] == [280, 288, 312]
+    # the conf's default is the reference's (-1 = "the library chooses"); what the library chooses is its own: 128 columns
+    # up to n = 16000, 192 above -- measured faster than the reference's 280 ... 312 at every size on an MI355X (round 6,
+    # capi.hip default_panel_width; the oracle keeps the reference's formula, tests/test_oracle.py)
+    assert [S.default_panel_width(n) for n in (2000, 8000, 16000, 20000)] == [128, 128, 128, 192]
 
 
 def test_product_does_not_touch_the_oracle():
