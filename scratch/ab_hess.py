@@ -30,7 +30,7 @@ for r in range(reps):
 """
 n, reps = sys.argv[1], sys.argv[2]
 for rnd in range(2):
-    for lib in ("", os.path.join(ROOT, "scratch", "ab", "libstarneig_amd_r5.so")):
+    for lib in ("", os.path.join(ROOT, "scratch", "ab", os.environ.get("AB_NAME", "libstarneig_amd_r5.so"))):
         env = dict(os.environ)
         if lib: env["SN_AB_LIB"] = lib
         else: env.pop("SN_AB_LIB", None)
