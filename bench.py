@@ -788,7 +788,7 @@ def main():
                 "critical_update_ms_per_step": gm / args.steps,
                 "side_stream_tflops": (gfs / (gs * 1e-3) / 1e12) if gs > 0 else None,
                 "note": "in situ, HIP events on the critical stream around every panel's launch(es); the same kernel "
-                        "alone with PMC MFMA-busy counters: profiles/r4_dgemm_mfma_utilisation.json, in situ over the first four panels: profiles/r6_pmc_mfma_in_situ.json (0.760 MFMA busy; the kernel is unchanged since round 4); why in situ reads "
+                        "alone with PMC MFMA-busy counters: profiles/r4_dgemm_mfma_utilisation.json, in situ over the first four panels: profiles/r6_pmc_mfma_in_situ.json (0.72 MFMA busy at the library's panel width, k = 384; 0.76 at the reference's, k = 624; the kernel is unchanged since round 4); why in situ reads "
                         "lower than alone (clock state after the HBM-bound panel): profiles/r4_gemm_phase_experiment.txt",
             }
         if world == 1 and args.host_api:
