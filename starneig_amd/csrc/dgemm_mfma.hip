@@ -90,10 +90,18 @@ void dgemm_splitk_kernel(int m, int n, int k, int kchunk, double alpha,
     // Tile order (speed only): the few column tiles of ONE row panel go to the same XCD back to back
     // (blocks b and b + 8 share an XCD), so the long operand panel -- 128 columns of the trailing matrix
     // in W = At^T (V T) -- comes from HBM once and from that XCD's L2 for the other column tiles.
+    // With fewer than 8 row panels that order would leave whole XCDs without work (one row panel: every active block
+    // on XCD 0 -- the 64 x n products of the QR step ran on 32 CUs until round 6): there the column tiles go round the
+    // XCDs instead.
     int const tiles_n = (n + BN - 1) / BN;
-    int const x = blockIdx.x % 8, j = blockIdx.x / 8;
-    int const bm = x + 8 * (j / tiles_n), bn = j % tiles_n;
-    if (bm >= tiles_m) return;
+    int bm, bn;
+    if (tiles_m >= 8) {
+        int const x = blockIdx.x % 8, j = blockIdx.x / 8;
+        bm = x + 8 * (j / tiles_n); bn = j % tiles_n;
+        if (bm >= tiles_m) return;
+    } else {
+        bm = blockIdx.x % tiles_m; bn = blockIdx.x / tiles_m;
+    }
     double const *Ak = TA ? A + k0 : A + (size_t)k0 * lda;
     double const *Bk = TB ? B + (size_t)k0 * ldb : B + k0;
     gemm_tile<BM, BN, KT, TA, TB, FLUSH>(m, n, kl, alpha, Ak, lda, Bk, ldb, 0.0, C, ldc, bm, bn);
@@ -229,7 +237,8 @@ static void launch_splitk(hipStream_t s, int m, int n, int k, int slices, double
         attr_set = true;
     }
     int const kchunk = (int)roundup((size_t)divceil(k, slices), 16);
-    int const tiles_m = divceil(m, BM), tiles = 8 * divceil(tiles_m, 8) * divceil(n, BN);   // (rounded up: see the kernel's tile order)
+    int const tiles_m = divceil(m, BM);
+    int const tiles = (tiles_m >= 8 ? 8 * divceil(tiles_m, 8) : tiles_m) * divceil(n, BN);   // (rounded up: see the kernel's tile order)
     int const nsl = divceil(k, kchunk);
     double *planes = splitk_planes(s, (size_t)nsl * m * n);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, nsl), dim3(256), Cfg::LDS_BYTES, s,
@@ -255,8 +264,8 @@ static void dispatch(hipStream_t s, int m, int n, int k, double alpha,
             launch_splitk<128, 64, TA, TB>(s, m, n, k, divceil(k, kchunk), alpha, A, lda, B, ldb, C, ldc);
             return;
         }
-        if (t64 <= 64) {
-            int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, 1024 / t64));
+        if (t64 <= 64 || m <= 64) {       // (one row of 64 x 64 tiles: W = (V T)^T A of the QR step, bound by reading A)
+            int const slices = (int)std::min<long>(divceil(k, 512), std::max<long>(1, (t64 <= 64 ? 1024 : 2048) / t64));
             launch_splitk<64, 64, TA, TB>(s, m, n, k, slices, alpha, A, lda, B, ldb, C, ldc);
             return;
         }

@@ -42,10 +42,23 @@ constexpr int QNB = 64;             // panel width
 constexpr int QROWS = 256;          // rows of one workgroup of the panel kernel
 constexpr int QP = QNB;             // partial record of one workgroup: index k = dot with column k, index jj = sum of squares
 
-__device__ inline double wave_sum(double v)
+// sum over the 16 lanes of a DPP row (every lane of the row gets it): VALU only, no LDS crossbar and no wait -- the
+// 64 sums of one launch of the panel kernel interleave (a chain of six __shfl_xor steps each cost 0.55 us a column)
+template <int CTRL>
+__device__ __forceinline__ double qr_dpp(double x)
 {
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += qr_dpp<0x128>(x);   // row_ror:8
+    x += qr_dpp<0x124>(x);   // row_ror:4
+    x += qr_dpp<0x122>(x);   // row_ror:2
+    x += qr_dpp<0x121>(x);   // row_ror:1
+    return x;
 }
 
 // Launch jj = 0..nb of one panel (rows/columns from p0):
@@ -60,9 +73,9 @@ __global__ __launch_bounds__(QROWS) void ht_qr_col_kernel(int n, int p0, int nb,
     double const *__restrict__ prow_in, double *__restrict__ prow_out, int nwg)
 {
     __shared__ double w[QNB];
-    __shared__ double red[QNB][QROWS / 64];
+    __shared__ double red[QNB][QROWS / 16 + 1];        // one partial per DPP row of 16 lanes
     __shared__ double sumsq;
-    int const tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int const tid = threadIdx.x, lane = tid & 63;
     int const i = p0 + blockIdx.x * QROWS + tid;        // global row
     bool const valid = i < n;
     double coef = 0.0;
@@ -92,25 +105,43 @@ __global__ __launch_bounds__(QROWS) void ht_qr_col_kernel(int n, int p0, int nb,
         }
     }
     if (jj < nb) {
+        // The thread's row of the panel goes through registers: all its loads are issued before the first use (one
+        // memory latency a launch; a loop of load - update - store - sum over the columns paid one per column, as the
+        // stores to B keep the next load behind them: 24.5 us a launch at n = 8000 until round 6).  The loops are
+        // unrolled over all QNB columns so that the register array keeps static indices.
         int const pdn = p0 + jj;
+        double a[QNB];
+        double const *Bi = B + (size_t)p0 * ldb + i;
+#pragma unroll
+        for (int k = 0; k < QNB; k++) {
+            a[k] = 0.0;
+            if (valid && k >= jj && k < nb) a[k] = Bi[(size_t)k * ldb];
+        }
+        if (kind) {
+            double const c = kind == 2 ? coef : 1.0;
+#pragma unroll
+            for (int k = 0; k < QNB; k++)
+                if (k >= jj && k < nb) { a[k] -= c * w[k]; B[(size_t)(p0 + k) * ldb + i] = a[k]; }
+        }
         double xn = 0.0;
-        for (int k = jj; k < nb; k++) {
-            double a = 0.0;
-            if (valid) {
-                size_t const off = (size_t)(p0 + k) * ldb + i;
-                a = B[off];
-                if (kind == 2) { a -= coef * w[k]; B[off] = a; }
-                else if (kind == 1) { a -= w[k]; B[off] = a; }
-                if (i == pdn) prow_out[k] = a;
+#pragma unroll
+        for (int k = 0; k < QNB; k++) if (k == jj) xn = a[k];
+        if (!(valid && i > pdn)) xn = 0.0;
+        if (valid && i == pdn) {
+#pragma unroll
+            for (int k = 0; k < QNB; k++) if (k >= jj && k < nb) prow_out[k] = a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < QNB; k++) {
+            if (k >= jj && k < nb) {
+                double const p = row16_sum(xn * a[k]);
+                if ((lane & 15) == 0) red[k][tid >> 4] = p;
             }
-            if (k == jj) xn = (valid && i > pdn) ? a : 0.0;
-            double const p = wave_sum(xn * a);
-            if (lane == 0) red[k][wv] = p;
         }
         __syncthreads();
         if (tid >= jj && tid < nb) {
             double p = 0.0;
-            for (int q = 0; q < QROWS / 64; q++) p += red[tid][q];
+            for (int q = 0; q < QROWS / 16; q++) p += red[tid][q];
             part_out[(size_t)blockIdx.x * QP + tid] = p;
         }
     }
