@@ -67,25 +67,43 @@ __device__ __forceinline__ double row16_sum(double x)
 //   jj < nb: sums of column jj on the updated data: S = sum x_i^2 and D_k = sum x_i a_ik (rows below
 //            the diagonal), and the pivot row itself (prow), so that no workgroup reads what another
 //            one writes in the same launch.
-__global__ __launch_bounds__(QROWS) void ht_qr_col_kernel(int n, int p0, int nb, int jj,
+// A workgroup is QROWS rows x QCG column groups (1024 threads): the thread of row r and group cg holds the columns
+// k = QCG u + cg of its row in registers -- every load of a launch in flight at once, QNB / QCG dependent steps a thread
+// instead of QNB.  (Round 6.  Before: one thread a row, a loop of load - update - store - sum over the columns: the stores
+// to B kept the next load behind them and each of the 64 sums was a chain of six __shfl_xor steps -- 0.55 us per
+// remaining column, 24.5 us a launch at n = 8000.)
+constexpr int QCG = 4, QCPT = QNB / QCG;
+__global__ __launch_bounds__(QROWS * QCG) void ht_qr_col_kernel(int n, int p0, int nb, int jj,
     double *__restrict__ B, int ldb, double *__restrict__ Vp, int ldp, double *__restrict__ tau,
     double const *__restrict__ part_in, double *__restrict__ part_out,
     double const *__restrict__ prow_in, double *__restrict__ prow_out, int nwg)
 {
     __shared__ double w[QNB];
     __shared__ double red[QNB][QROWS / 16 + 1];        // one partial per DPP row of 16 lanes
+    __shared__ double xs[QROWS];                        // column jj of the workgroup's rows, by the group that owns it
     __shared__ double sumsq;
-    int const tid = threadIdx.x, lane = tid & 63;
-    int const i = p0 + blockIdx.x * QROWS + tid;        // global row
+    int const tid = threadIdx.x, row = tid & (QROWS - 1), cg = tid / QROWS;
+    int const i = p0 + blockIdx.x * QROWS + row;        // global row
     bool const valid = i < n;
     double coef = 0.0;
     int kind = 0;                                       // 1: pivot row, 2: below it
     if (jj > 0) {
         int const pc = jj - 1, pd = p0 + pc;
         double acc = 0.0;
-        if (tid >= pc && tid < nb)
-            for (int g = 0; g < nwg; g++) acc += part_in[(size_t)g * QP + tid];
+        if (tid >= pc && tid < nb) {
+            int g = 0;
+            for (; g + 8 <= nwg; g += 8) {              // (eight loads in flight, added in workgroup order)
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = part_in[(size_t)(g + u) * QP + tid];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += v[u];
+            }
+            for (; g < nwg; g++) acc += part_in[(size_t)g * QP + tid];
+        }
         if (tid == pc) sumsq = acc;
+        size_t const off = (size_t)(p0 + pc) * ldb + i;
+        double const braw = (valid && i > pd) ? B[off] : 0.0;     // read by all four groups of the row before group 0 rewrites it
         __syncthreads();
         double const S = sumsq, alpha = prow_in[pc];
         double beta = alpha, t = 0.0, scale = 0.0;
@@ -97,45 +115,56 @@ __global__ __launch_bounds__(QROWS) void ht_qr_col_kernel(int n, int p0, int nb,
         if (tid >= jj && tid < nb) w[tid] = t * (prow_in[tid] + scale * acc);
         __syncthreads();
         if (valid) {
-            size_t const off = (size_t)(p0 + pc) * ldb + i;
             double v = 0.0;
-            if (i > pd) { coef = B[off] * scale; kind = 2; B[off] = 0.0; v = coef; }
-            else if (i == pd) { kind = 1; B[off] = beta; tau[pc] = t; v = 1.0; }
-            Vp[(size_t)pc * ldp + (i - p0)] = v;
+            if (i > pd) { coef = braw * scale; kind = 2; v = coef; }
+            else if (i == pd) { kind = 1; v = 1.0; }
+            if (cg == 0) {
+                if (kind == 2) B[off] = 0.0;
+                else if (kind == 1) { B[off] = beta; tau[pc] = t; }
+                Vp[(size_t)pc * ldp + (i - p0)] = v;
+            }
         }
     }
     if (jj < nb) {
-        // The thread's row of the panel goes through registers: all its loads are issued before the first use (one
-        // memory latency a launch; a loop of load - update - store - sum over the columns paid one per column, as the
-        // stores to B keep the next load behind them: 24.5 us a launch at n = 8000 until round 6).  The loops are
-        // unrolled over all QNB columns so that the register array keeps static indices.
+        // (No divergent branch assigns to the register array: loads from clamped addresses and selects -- with
+        // conditional assignments the compiler kept the array as one 32-register value and spilled it at every merge.)
         int const pdn = p0 + jj;
-        double a[QNB];
-        double const *Bi = B + (size_t)p0 * ldb + i;
+        double a[QCPT];
+        bool act[QCPT];
+        double const *Bi = B + (size_t)p0 * ldb + min(i, n - 1);
+        double const c = kind == 2 ? coef : (kind == 1 ? 1.0 : 0.0);
 #pragma unroll
-        for (int k = 0; k < QNB; k++) {
-            a[k] = 0.0;
-            if (valid && k >= jj && k < nb) a[k] = Bi[(size_t)k * ldb];
+        for (int u = 0; u < QCPT; u++) {
+            int const k = QCG * u + cg;
+            act[u] = valid && k >= jj && k < nb;
+            double const v = Bi[(size_t)min(max(k, jj), nb - 1) * ldb];
+            a[u] = act[u] ? v : 0.0;
         }
-        if (kind) {
-            double const c = kind == 2 ? coef : 1.0;
 #pragma unroll
-            for (int k = 0; k < QNB; k++)
-                if (k >= jj && k < nb) { a[k] -= c * w[k]; B[(size_t)(p0 + k) * ldb + i] = a[k]; }
+        for (int u = 0; u < QCPT; u++) {
+            int const k = QCG * u + cg;
+            double const wk = w[k];
+            a[u] -= c * ((jj > 0 && act[u]) ? wk : 0.0);
+            if (act[u] && kind) B[(size_t)(p0 + k) * ldb + i] = a[u];
         }
-        double xn = 0.0;
+        if (cg == (jj & (QCG - 1))) {
+            double x = 0.0;
 #pragma unroll
-        for (int k = 0; k < QNB; k++) if (k == jj) xn = a[k];
-        if (!(valid && i > pdn)) xn = 0.0;
+            for (int u = 0; u < QCPT; u++) x = (u == jj / QCG) ? a[u] : x;
+            xs[row] = (valid && i > pdn) ? x : 0.0;
+        }
         if (valid && i == pdn) {
 #pragma unroll
-            for (int k = 0; k < QNB; k++) if (k >= jj && k < nb) prow_out[k] = a[k];
+            for (int u = 0; u < QCPT; u++) { int const k = QCG * u + cg; if (act[u]) prow_out[k] = a[u]; }
         }
+        __syncthreads();
+        double const xn = xs[row];
 #pragma unroll
-        for (int k = 0; k < QNB; k++) {
+        for (int u = 0; u < QCPT; u++) {
+            int const k = QCG * u + cg;
             if (k >= jj && k < nb) {
-                double const p = row16_sum(xn * a[k]);
-                if ((lane & 15) == 0) red[k][tid >> 4] = p;
+                double const p = row16_sum(xn * a[u]);
+                if ((row & 15) == 0) red[k][row >> 4] = p;
             }
         }
         __syncthreads();
@@ -893,7 +922,11 @@ void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, doub
     // Only the trailing columns of B feed the next panel: they stay on `s` behind the panel's column chain.  A and Q
     // -- three quarters of the step's flops, rank-64 updates bound by HBM -- take their updates on the side stream
     // beside the next panels' latency-bound chains, from the second of two sets of panel factors (round 6: the step
-    // 0.57 -> 0.3x s at n = 8000; everything on one stream before).
+    // 0.57 -> 0.18 s at n = 8000 with the split-K tile order of dgemm_mfma.hip and the column kernel above; everything on
+    // one stream before).
+    // (Round 6, tried: a CU-masked side stream that leaves every fifth CU to the column chain -- its launches wait 30 us
+    // instead of 10 for a free CU while the GEMMs of the previous panel run.  One more hardware queue in the process
+    // doubled stage 1 of the two-stage path behind it, 1.2 -> 2.3 s at n = 8000: not kept.)
     int const ldp = ws.ldp;
     hipStream_t const q = ws.side;
     int pc = 0;
@@ -902,7 +935,7 @@ void ht_qr_step(hipStream_t s, HtWorkspace &ws, int n, double *dA, int ldA, doub
         double *Vp = b ? ws.Vp1 : ws.Vp, *VT = b ? ws.VT1 : ws.VT;
         if (pc >= 2) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.e_pfree[b], 0));     // the side stream is through with this set
         for (int jj = 0; jj <= nb; jj++)
-            hipLaunchKernelGGL(ht_qr_col_kernel, dim3(nwg), dim3(QROWS), 0, s, n, p0, nb, jj, dB, ldB,
+            hipLaunchKernelGGL(ht_qr_col_kernel, dim3(nwg), dim3(QROWS * QCG), 0, s, n, p0, nb, jj, dB, ldB,
                 Vp, ldp, ws.tau, ws.part[(jj + 1) & 1], ws.part[jj & 1], ws.prow[(jj + 1) & 1], ws.prow[jj & 1], nwg);
         dgemm(s, 'T', 'N', nb, nb, m, 1.0, Vp, ldp, Vp, ldp, 0.0, ws.G, QNB);
         hipLaunchKernelGGL(ht_qr_tfactor_kernel, dim3(1), dim3(64), 0, s, nb, ws.G, ws.tau, ws.T);
