@@ -11,13 +11,16 @@
 //   overhanging column (rows p .. p + r - 1, p = j + 1 + t r), applied to the rows of A, B; the "opposite"
 //   reflector from the right whose first column is orthogonal to rows 2 .. r of the r x r block of B (QR of those
 //   rows in LDS: no solve with B, singular B included), applied to the columns of B, A.  Sweep j + 1 runs position
-//   t while sweep j runs position t + 2: wavefronts of ~n / (2 r) independent steps, three launches each (left
-//   reflectors; opposite reflectors under the left application; right application).  Q and Z take the reflectors
+//   t while sweep j runs position t + 2: wavefronts of ~n / (2 r) independent steps, three launches each (round 6:
+//   the second half of the 75 us factorisation behind the opposite reflectors beside the left application; the near
+//   part of the right application; the first half of the NEXT wavefront's factorisations beside the far part of the
+//   right application -- scratch/ht2_overlap.py).  Q and Z take the reflectors
 //   of 64 sweeps at a time as compact-WY blocks on a second stream -- and so do the rows of A and B ABOVE the first
 //   row a group's left reflectors can reach (round 6): those rows only ever see right reflectors again, half of the
 //   right application's bytes leave the chase.
-// scratch/ht2_proto.py, scratch/ht2_lag.py and scratch/ht2_defer.py are the numpy statements of the algorithm, of this
-// order and of the deferred rows (tests/test_ht_twostage_prototype.py).
+// scratch/ht2_proto.py, scratch/ht2_lag.py, scratch/ht2_defer.py and scratch/ht2_overlap.py are the numpy statements of the
+// algorithm, of the wavefront order, of the deferred rows and of the order of a wavefront's launches
+// (tests/test_ht_twostage_prototype.py).
 #include "common.h"
 #include "tuning.h"
 #include <algorithm>
@@ -74,11 +77,14 @@ __device__ __forceinline__ double row16_sum(double x)
 // and a step touches LDS only for the pivot column.  The group of column c + 1 forms that column's scalars and
 // publishes it (unscaled, with R above the diagonal) right after its own update: ONE barrier per column.
 template <int MR>
-__device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *scl)
+__device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *scl, int cbeg = 0, int cend = 1 << 30)
 {
+    // Columns [cbeg, cend) only (stage 2 splits the factorisation behind an opposite reflector over two launches): a
+    // call that stops early leaves the columns from cend on in P as they stand, UNpublished; the call that continues
+    // publishes column cbeg first.
     __shared__ double piv[2][2];
     int const tid = threadIdx.x, l = tid & 15, g = tid >> 4;
-    int const kref = min(m - 1, k);
+    int const kref = min(m - 1, k), c_lo = min(cbeg, kref), c_hi = min(cend, kref);
     double x[MR];
     #pragma unroll
     for (int r = 0; r < MR; r++) { int const i = l + 16 * r; x[r] = (g < k && i < m) ? P[g * ldp + i] : 0.0; }
@@ -111,9 +117,9 @@ __device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *
         for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i < m) P[c * ldp + i] = (i == c) ? beta : x[r]; }
         if (l == 0) { tau[c] = t; scl[c] = scale; piv[c & 1][0] = t; piv[c & 1][1] = scale; }
     };
-    if (g == 0 && kref > 0) publish(0);
+    if (g == c_lo && c_lo < kref) publish(c_lo);
     __syncthreads();
-    for (int c = 0; c < kref; c++) {
+    for (int c = c_lo; c < c_hi; c++) {
         double const t = piv[c & 1][0], scale = piv[c & 1][1];
         if (g > c && g < k) {
             if (t != 0.0) {
@@ -132,14 +138,14 @@ __device__ void group_qr(double *P, int ldp, int m, int k, double *tau, double *
                 #pragma unroll
                 for (int r = 0; r < MR; r++) { int const i = l + 16 * r; x[r] -= wsc * pc[r]; if (i == c) x[r] -= w; }
             }
-            if (g == c + 1 && c + 1 < kref) publish(c + 1);
+            if (g == c + 1 && c + 1 < c_hi) publish(c + 1);
         }
         __syncthreads();
     }
-    if (g >= kref && g < k) {
+    if (g >= c_hi && g < k) {
         #pragma unroll
         for (int r = 0; r < MR; r++) { int const i = l + 16 * r; if (i < m) P[g * ldp + i] = x[r]; }
-        if (l == 0) { tau[g] = 0.0; scl[g] = 0.0; }
+        if (l == 0 && g >= kref) { tau[g] = 0.0; scl[g] = 0.0; }
     }
     __syncthreads();
 }
@@ -313,9 +319,13 @@ __device__ __forceinline__ bool step_of(Wave2 const &w, int k, int &p, int &p1, 
     return true;
 }
 
-// X(p:p1, cb:n) <- (I - tau v v^T) X for X = A (z = 0, cb = c0 + 1) and X = B (z = 1, cb = p): 16 lanes per
-// column, four rows each (DPP sums); a workgroup of 1024 threads takes a chunk of LEFT_CHUNK columns, four per 16-lane
-// group, all in flight together
+// X(p:p1, cols) <- (I - tau v v^T) X for X = A (z = 0) and X = B (z = 1), WITHOUT the step's own diagonal blocks
+// A(I, I), B(I, I) (they take H in ht2_near_kernel, see the schedule above the wavefront loop): A: the columns
+// [c0 + 1, p) -- chunk 0, at most r - 1 of them -- and [p1, n); B: [p1, n).  16 lanes per column, four rows each (DPP
+// sums); a workgroup of 1024 threads takes a chunk of LEFT_CHUNK columns, four per 16-lane group, all in flight
+// together.  (The 512-byte pieces of a column start on no particular boundary: 5 lines of 128 bytes for 4 -- in a
+// stand-alone copy of this access pattern every mapping tried moved 3.6 TB/s at n = 12000 where an in-place stream
+// over as many bytes moves 4.7, scratch/micro/ht2_apply_bw.hip.)
 constexpr int LEFT_CHUNK = 128;
 __device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chunk, int z, double *__restrict__ A, int lda,
     double *__restrict__ B, int ldb, double const *__restrict__ HV, double const *__restrict__ HT)
@@ -326,9 +336,12 @@ __device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chun
     if (tau == 0.0) return;
     bool const isB = z == 1;
     double *X = isB ? B : A;
-    int const ld = isB ? ldb : lda, cb = isB ? p : c0 + 1, len = p1 - p;
-    int const cbeg = cb + chunk * LEFT_CHUNK;
-    if (cbeg >= w.n) return;
+    int const ld = isB ? ldb : lda, len = p1 - p;
+    int cbeg, cend = w.n;
+    if (isB) cbeg = p1 + chunk * LEFT_CHUNK;
+    else if (chunk == 0) { cbeg = c0 + 1; cend = p; }
+    else cbeg = p1 + (chunk - 1) * LEFT_CHUNK;
+    if (cbeg >= cend) return;
     int const tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;            // 64 column groups per block
     int const r0 = 4 * l16;
     double v[4];
@@ -342,7 +355,7 @@ __device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chun
         double const *x = X + (size_t)c * ld + p + r0;
         d[u] = 0.0;
         #pragma unroll
-        for (int q = 0; q < 4; q++) { y[u][q] = (c < w.n && r0 + q < len) ? x[q] : 0.0; d[u] += v[q] * y[u][q]; }
+        for (int q = 0; q < 4; q++) { y[u][q] = (c < cend && r0 + q < len) ? x[q] : 0.0; d[u] += v[q] * y[u][q]; }
     }
     #pragma unroll
     for (int u = 0; u < NC; u++) d[u] = row16_sum(d[u]) * tau;
@@ -351,74 +364,82 @@ __device__ __forceinline__ void apply_left_chunk(Wave2 const &w, int k, int chun
         int const c = cbeg + grp + 64 * u;
         double *x = X + (size_t)c * ld + p + r0;
         #pragma unroll
-        for (int q = 0; q < 4; q++) if (c < w.n && r0 + q < len) x[q] = y[u][q] - d[u] * v[q];
+        for (int q = 0; q < 4; q++) if (c < cend && r0 + q < len) x[q] = y[u][q] - d[u] * v[q];
     }
 }
+// (one workgroup per (chunk, step, matrix) of launch M2; nchunk = divceil(n, LEFT_CHUNK) + 1)
 
-// X(top:rows, p:p1) <- X (I - tau v v^T) for up to three targets: a workgroup takes 64 rows, wave q of its four the
-// columns 16 q .. 16 q + 15 of the block (lane = row: every load is 512 contiguous bytes), the partial row sums
-// meet in LDS.  kind 0: all nrows rows (Q, Z); kind 1: rows [top, p1) and the first column of the block cleaned
-// below its diagonal entry (B after the opposite reflector); kind 2: rows [top, min(p1 + r, n)) (A).
-// top = (j / GS) GS + 1 (kinds 1, 2): the rows above the first row any left reflector of the sweep's GROUP -- or of a
+// The FAR part of a step's right application: X(top : p - (r - 1), p:p1) <- X (I - tau v v^T) for X = B (z = 0) and
+// X = A (z = 1); the rows from p - (r - 1) on are the near part (ht2_near_kernel).  A quarter of a 1024-thread
+// workgroup (256 threads, t256) takes 64 rows: wave q of its four the columns 16 q .. 16 q + 15 of the block (lane = row:
+// every load is 512 contiguous bytes), the partial row sums meet in LDS.  No thread leaves before the barrier.
+// top = (j / GS) GS + 1: the rows above the first row any left reflector of the sweep's GROUP -- or of a
 // later one -- can reach.  From the group's first wavefront on they see right reflectors only (a sweep j' of an
 // older group is at p' = j' + 1 + (tau - 2 j') r >= top by then), so they take the group's opposite reflectors
 // later, as compact-WY blocks beside Z (close_group): the blocks of OLDER groups that overlap one of them in columns
 // were generated, and applied to these rows at once, before it; later ones are disjoint from it
 // (scratch/ht2_defer.py runs this order in numpy, and the same deferral of the LEFT reflectors' far columns as the
 // negative control: a right reflector that straddles the boundary mixes updated and stale columns).
-struct RightTargets { double *X[3]; int ld[3]; int kind[3]; };
-__global__ __launch_bounds__(256) void ht2_apply_right_kernel(Wave2 w, RightTargets tg, int nrows,
-    double const *__restrict__ RV, double const *__restrict__ RT)
+__device__ __forceinline__ void far_tile(Wave2 const &w, int k, int z, int tile, int quarter, int t256,
+    double *__restrict__ A, int lda, double *__restrict__ B, int ldb, double const *__restrict__ RV, double const *__restrict__ RT,
+    double (*s_d)[4][64])
 {
-    __shared__ double s_d[4][64];
-    int const k = blockIdx.y;
-    int p, p1, c0, ridx;
-    if (!step_of(w, k, p, p1, c0, ridx)) return;
-    double const tau = RT[ridx];
-    int const len = p1 - p, z = blockIdx.z;
-    double *X = tg.X[z];
-    int const ld = tg.ld[z], kind = tg.kind[z];
-    int const rows = kind == 0 ? nrows : (kind == 1 ? p1 : min(p1 + R2, w.n));
+    int p = 0, p1 = 0, c0, ridx = 0;
+    bool const ok = step_of(w, k, p, p1, c0, ridx);
+    double const tau = ok ? RT[ridx] : 0.0;
+    int const len = p1 - p;
+    double *X = z == 0 ? B : A;
+    int const ld = z == 0 ? ldb : lda;
     // (row tiles start on a multiple of 16 rows at or below top: 128-byte lines; the rows below top are masked)
-    int const top = kind == 0 ? 0 : ((w.jlo + k) / GS) * GS + 1, base = top & ~15;
-    if (base + blockIdx.x * 64 >= rows) return;
-    int const lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    int const row = base + blockIdx.x * 64 + lane, q0 = 16 * part;
-    bool const live = row < rows && row >= top;
+    int const top = ((w.jlo + k) / GS) * GS + 1, base = top & ~15;
+    int const rows = max(top, p - (R2 - 1));
+    // (the wave's column offset made uniform for the compiler: the reflector entries are scalar loads, not 32 more
+    // vector registers under the launch's 64)
+    int const lane = t256 & 63, part = __builtin_amdgcn_readfirstlane(t256 >> 6);
+    int const row = base + tile * 64 + lane, q0 = 16 * part;
+    bool const live = ok && tau != 0.0 && row < rows && row >= top;
     double *x = X + (size_t)(p + q0) * ld + row;
-    if (tau != 0.0) {
-        double y[16], v[16], d = 0.0;
-        #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            v[q] = q0 + q < len ? RV[(size_t)ridx * R2 + q0 + q] : 0.0;
-            y[q] = (live && q0 + q < len) ? x[(size_t)q * ld] : 0.0;
-            d += y[q] * v[q];
-        }
-        s_d[part][lane] = d;
-        __syncthreads();
-        d = ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane])) * tau;
-        #pragma unroll
-        for (int q = 0; q < 16; q++) if (live && q0 + q < len) x[(size_t)q * ld] = y[q] - d * v[q];
+    double y[16], v[16], d = 0.0;
+    #pragma unroll
+    for (int q = 0; q < 16; q++) {
+        v[q] = (ok && q0 + q < len) ? RV[(size_t)ridx * R2 + q0 + q] : 0.0;
+        y[q] = (live && q0 + q < len) ? x[(size_t)q * ld] : 0.0;
+        d += y[q] * v[q];
     }
-    if (kind == 1 && part == 0 && live && row > p && row < p1) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
+    s_d[quarter][part][lane] = d;
+    __syncthreads();
+    d = ((s_d[quarter][0][lane] + s_d[quarter][1][lane]) + (s_d[quarter][2][lane] + s_d[quarter][3][lane])) * tau;
+    #pragma unroll
+    for (int q = 0; q < 16; q++) if (live && q0 + q < len) x[(size_t)q * ld] = y[q] - d * v[q];
 }
 
-// The reflectors of a wavefront in two kernels.  (1) ht2_genh_kernel, one small workgroup per step: the left reflector
-// H = I - th v v^T from A's overhanging column (v, th -> the step's entry of HV, HT; the column is reduced in place)
-// and a copy of the step's block Bb = B(p:p1, p:p1) as it stands BEFORE H.  (2) ht2_geng_left_kernel: its first
-// `count` workgroups form the opposite reflectors from those copies -- M = H Bb in LDS, x orthogonal to rows 1 ..
-// len-1 of M (QR of those rows, transposed; x = the last column of the full Q), G = I - tz w w^T with G e_1 = +-x
-// (w, tz -> GV, GT) --, 75 us of latency on 60 of 256 CUs, WHILE the rest of its workgroups apply the left reflectors
-// to the rows of A and B, the HBM-bound part: a wavefront is 5 us + max(75 us, left) + right instead of 75 us + left +
-// right.  Bb is a full block (the bulge of B travels with the sweep; a step restores its first column only), so
-// there is no triangular short cut to x.
-__global__ __launch_bounds__(256) void ht2_genh_kernel(Wave2 w, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
-    double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ Bcopy)
+// The reflectors of a step.  The left reflector H = I - th v v^T comes from A's overhanging column (v, th -> the step's
+// entry of HV, HT; the column is reduced in place).  The opposite reflector: M = H Bb in LDS for the step's block
+// Bb = B(p:p1, p:p1) as it stands BEFORE H, x orthogonal to rows 1 .. len-1 of M (QR of those rows, transposed;
+// x = the last column of the full Q), G = I - tz w w^T with G e_1 = +-x (w, tz -> GV, GT).  Bb is a full block (the
+// bulge of B travels with the sweep; a step restores its first column only), so there is no triangular short cut
+// to x: 75 us of latency, one workgroup a step on at most n / 127 of the 256 CUs.  They are split over TWO launches so
+// that they hide under both HBM-bound applications of the chase (the schedule above the wavefront loop):
+// gen_first -- H, M, the first GEN_SPLIT columns of the factorisation; its state (the panel, tau, scl) to `state` --
+// beside the far part of the previous wavefront's right application, gen_second -- the rest -- beside the left
+// application of its own wavefront.
+constexpr int GEN_LQ = R2 + 1;
+constexpr int GEN_STATE = R2 * GEN_LQ + 2 * R2;       // doubles a step: the panel, tau, scl
+constexpr int GEN_SPLIT = 27;                         // (the early columns are the long ones: 27 of 63 are half of the time)
+// A wavefront whose left application alone outlasts the whole factorisation keeps it in the second launch (split 0:
+// gen_first forms H and M only) -- beside the shorter far part its workgroups only take CUs from it.
+constexpr double GEN_HIDE_US = 100.0, LEFT_BYTES_PER_US = 3.8e6;
+__device__ void gen_first(Wave2 const &w, int k, int split, double *__restrict__ A, int lda, double const *__restrict__ B, int ldb,
+    double *__restrict__ HV, double *__restrict__ HT, double *__restrict__ state)
 {
-    int const k = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int LQ = GEN_LQ;
+    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
+    __shared__ double s_th;
+    int const tid = threadIdx.x;
     int p, p1, c0, ridx;
     if (!step_of(w, k, p, p1, c0, ridx)) return;
-    int const len = p1 - p;
+    int const len = p1 - p, kq = len - 1;
     if (tid < 64) {
         int const lane = tid;
         double *col = A + (size_t)c0 * lda + p;
@@ -427,42 +448,15 @@ __global__ __launch_bounds__(256) void ht2_genh_kernel(Wave2 w, double *__restri
         double const alpha = __shfl(x, 0);
         double t = 0.0, beta = alpha, scale = 0.0;
         if (ss != 0.0) { beta = -copysign(sqrt(alpha * alpha + ss), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
-        HV[(size_t)ridx * R2 + lane] = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
-        if (lane == 0) HT[ridx] = t;
+        double const v = lane == 0 ? 1.0 : (lane < len ? x * scale : 0.0);
+        HV[(size_t)ridx * R2 + lane] = v;
+        s_v[lane] = v;
+        if (lane == 0) { HT[ridx] = t; s_th = t; }
         if (lane < len) col[lane] = lane == 0 ? beta : 0.0;
     }
-    double *Bc = Bcopy + (size_t)k * R2 * R2;
-    for (int idx = tid; idx < len * len; idx += 256) {
+    for (int idx = tid; idx < len * len; idx += QT) {
         int const i = idx % len, j = idx / len;
-        Bc[j * R2 + i] = B[(size_t)(p + j) * ldb + p + i];
-    }
-}
-
-__global__ __launch_bounds__(QT, 8) void ht2_geng_left_kernel(Wave2 w, int nchunk, double *__restrict__ A, int lda, double *__restrict__ B, int ldb,
-    double const *__restrict__ HV, double const *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT,
-    double const *__restrict__ Bcopy)
-{
-    if ((int)blockIdx.x >= w.count) {
-        int const idx = blockIdx.x - w.count, chunk = idx % nchunk, rest = idx / nchunk;
-        apply_left_chunk(w, rest % w.count, chunk, rest / w.count, A, lda, B, ldb, HV, HT);
-        return;
-    }
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int LQ = R2 + 1;
-    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2, *s_v = scl + R2, *s_u = s_v + R2;
-    int const k = blockIdx.x, tid = threadIdx.x;
-    int p, p1, c0, ridx;
-    if (!step_of(w, k, p, p1, c0, ridx)) return;
-    GV += (size_t)ridx * R2; GT += ridx;
-    int const len = p1 - p, kq = len - 1;
-    double const s_th = HT[ridx];
-    if (tid < R2) s_v[tid] = HV[(size_t)ridx * R2 + tid];
-    {
-        double const *Bc = Bcopy + (size_t)k * R2 * R2;
-        for (int idx = tid; idx < len * len; idx += QT) {
-            int const i = idx % len, j = idx / len;
-            Bs[j * LQ + i] = Bc[j * R2 + i];
-        }
+        Bs[j * LQ + i] = B[(size_t)(p + j) * ldb + p + i];
     }
     __syncthreads();
     if (tid < len) {                       // u = v^T Bb
@@ -477,7 +471,28 @@ __global__ __launch_bounds__(QT, 8) void ht2_geng_left_kernel(Wave2 w, int nchun
         P[b * LQ + a] = Bs[a * LQ + b + 1] - s_v[b + 1] * s_u[a];
     }
     __syncthreads();
-    group_qr<R2 / 16>(P, LQ, len, kq, tau, scl);
+    group_qr<R2 / 16>(P, LQ, len, kq, tau, scl, 0, split);
+    double *st = state + (size_t)k * GEN_STATE;
+    for (int idx = tid; idx < R2 * LQ + 2 * R2; idx += QT)
+        st[idx] = idx < R2 * LQ ? P[idx] : (idx < R2 * LQ + R2 ? tau[idx - R2 * LQ] : scl[idx - R2 * LQ - R2]);
+}
+__device__ void gen_second(Wave2 const &w, int k, int split, double const *__restrict__ state, double *__restrict__ GV, double *__restrict__ GT)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int LQ = GEN_LQ;
+    double *P = lds, *Bs = P + R2 * LQ, *tau = Bs + R2 * LQ, *scl = tau + R2;
+    int const tid = threadIdx.x;
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    GV += (size_t)ridx * R2; GT += ridx;
+    int const len = p1 - p, kq = len - 1;
+    double const *st = state + (size_t)k * GEN_STATE;
+    for (int idx = tid; idx < R2 * LQ + 2 * R2; idx += QT) {
+        double const x = st[idx];
+        if (idx < R2 * LQ) P[idx] = x; else if (idx < R2 * LQ + R2) tau[idx - R2 * LQ] = x; else scl[idx - R2 * LQ - R2] = x;
+    }
+    __syncthreads();
+    group_qr<R2 / 16>(P, LQ, len, kq, tau, scl, split);
     if (tid < 16) {
         // e = H_0 ... H_{kq-1} e_{len-1}, four entries per lane of ONE 16-lane group (DPP sums); then the
         // reflector from x = e (dlarfg)
@@ -519,6 +534,87 @@ __global__ __launch_bounds__(QT, 8) void ht2_geng_left_kernel(Wave2 w, int nchun
     }
 }
 constexpr int GEN_LDS_BYTES = (2 * R2 * (R2 + 1) + 4 * R2 + 16) * 8;
+
+// Launch M1 of a wavefront: the first halves of the NEXT wavefront's generations (wn, one workgroup a step, first in
+// the grid) beside the far parts of THIS wavefront's right applications (wc: ntile4 workgroups of four row tiles a
+// step and matrix).  Launch M2: the second halves of a wavefront's generations beside its left applications.
+__global__ __launch_bounds__(QT, 8) void ht2_m1_kernel(Wave2 wn, int split, Wave2 wc, int ntile4, double *__restrict__ A, int lda, double *__restrict__ B, int ldb,
+    double *__restrict__ HV, double *__restrict__ HT, double const *__restrict__ GV, double const *__restrict__ GT, double *__restrict__ state)
+{
+    __shared__ double s_d[4][4][64];
+    if ((int)blockIdx.x < wn.count) { gen_first(wn, blockIdx.x, split, A, lda, B, ldb, HV, HT, state); return; }
+    int const idx = blockIdx.x - wn.count, tile4 = idx % ntile4, rest = idx / ntile4;
+    int const quarter = threadIdx.x >> 8;
+    far_tile(wc, rest % wc.count, rest / wc.count, 4 * tile4 + quarter, quarter, threadIdx.x & 255, A, lda, B, ldb, GV, GT, s_d);
+}
+__global__ __launch_bounds__(QT, 8) void ht2_m2_kernel(Wave2 w, int split, int nchunk, double *__restrict__ A, int lda, double *__restrict__ B, int ldb,
+    double const *__restrict__ HV, double const *__restrict__ HT, double *__restrict__ GV, double *__restrict__ GT, double const *__restrict__ state)
+{
+    if ((int)blockIdx.x < w.count) { gen_second(w, blockIdx.x, split, state, GV, GT); return; }
+    int const idx = blockIdx.x - w.count, chunk = idx % nchunk, rest = idx / nchunk;
+    apply_left_chunk(w, rest % w.count, chunk, rest / w.count, A, lda, B, ldb, HV, HT);
+}
+
+// The NEAR part of a step's right application, and before it the left reflector on the step's own diagonal blocks:
+//   tile 1 (rows I = [p, p1)):  X(I, I) <- H X(I, I), then X(I, I) <- X(I, I) G          (X = B: blockIdx.z 0, X = A: 1)
+//   tile 0 (rows [p - (r - 1), p), never above the group's top):  X(rows, I) <- X(rows, I) G
+//   tile 2 (A only, rows [p1, min(p1 + r, n))):                   A(rows, I) <- A(rows, I) G
+// and B(p + 1 : p1, p) = 0 exactly.  These are the entries the NEXT wavefront's reflectors are generated from
+// (A(p + r : p + 2r, p) for the sweep's own next left reflector, B(p - r + 1 : p + 1, p) as the last column of the
+// younger neighbour's next block) -- everything else of the right application is the far part
+// (ht2_apply_right_kernel, far = 1) and waits on the second stream.  256 threads: lane = row of the tile (512
+// contiguous bytes a load; the tiles start at p, not on a 128-byte boundary -- 3 x 32 KB a step), wave q = the columns
+// p + 16 q .. p + 16 q + 15; the column sums of H are full-wave sums (DPP rows + two shuffles), the row sums of G meet
+// in LDS.
+__device__ __forceinline__ double near_wave_sum(double x)
+{
+    x = row16_sum(x);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+__global__ __launch_bounds__(256) void ht2_near_kernel(Wave2 w, double *__restrict__ A, int lda, double *__restrict__ B, int ldb,
+    double const *__restrict__ HV, double const *__restrict__ HT, double const *__restrict__ GV, double const *__restrict__ GT)
+{
+    __shared__ double s_d[4][64];
+    int const tile = blockIdx.x, k = blockIdx.y, z = blockIdx.z;
+    int p, p1, c0, ridx;
+    if (!step_of(w, k, p, p1, c0, ridx)) return;
+    if (z == 0 && tile == 2) return;
+    int const len = p1 - p;
+    double *X = z == 0 ? B : A;
+    int const ld = z == 0 ? ldb : lda;
+    int const top = ((w.jlo + k) / GS) * GS + 1, cut = max(top, p - (R2 - 1));
+    int const lane = threadIdx.x & 63, wq = threadIdx.x >> 6, q0 = 16 * wq;
+    int const row = tile == 0 ? p - R2 + lane : (tile == 1 ? p + lane : p1 + lane);
+    int const hi = tile == 0 ? p : (tile == 1 ? p1 : min(p1 + R2, w.n)), lo = tile == 0 ? cut : (tile == 1 ? p : p1);
+    bool const live = row >= lo && row < hi;
+    double *x = X + (size_t)(p + q0) * ld + row;
+    double y[16], g[16];
+    #pragma unroll
+    for (int q = 0; q < 16; q++) {
+        g[q] = q0 + q < len ? GV[(size_t)ridx * R2 + q0 + q] : 0.0;
+        y[q] = (live && q0 + q < len) ? x[(size_t)q * ld] : 0.0;
+    }
+    if (tile == 1) {
+        double const th = HT[ridx];
+        if (th != 0.0) {
+            double const v = lane < len ? HV[(size_t)ridx * R2 + lane] : 0.0;
+            #pragma unroll
+            for (int q = 0; q < 16; q++) y[q] -= (th * near_wave_sum(v * y[q])) * v;
+        }
+    }
+    double const tz = GT[ridx];
+    double d = 0.0;
+    #pragma unroll
+    for (int q = 0; q < 16; q++) d += y[q] * g[q];
+    s_d[wq][lane] = d;
+    __syncthreads();
+    d = ((s_d[0][lane] + s_d[1][lane]) + (s_d[2][lane] + s_d[3][lane])) * tz;
+    #pragma unroll
+    for (int q = 0; q < 16; q++) if (live && q0 + q < len) x[(size_t)q * ld] = y[q] - d * g[q];
+    if (z == 0 && tile == 1 && wq == 0 && live && row > p) x[0] = 0.0;            // B(p+1:p1, p) = 0 exactly
+}
 
 // Q and Z do not take part in the chase: the reflectors of a group of GS sweeps are applied to them once the group
 // is through, position by position as compact-WY blocks.  The reflectors (j0 + jj, t), jj = 0 .. k-1, of position t
@@ -710,7 +806,7 @@ struct Ht2Workspace {
     double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
     double *HV = nullptr, *HT = nullptr, *GV = nullptr, *GT = nullptr;      // stage 2: nslot groups of GS x tstride reflectors
     double *Vb = nullptr, *VTb = nullptr;           // stage 2: the compact-WY blocks of the group being applied (2 x tstride)
-    double *Bcopy = nullptr;                        // stage 2: the steps' blocks of B as they stand before the left reflectors
+    double *gstate = nullptr;                       // stage 2: the half-finished factorisations between the two launches of a generation (GEN_STATE doubles a step)
     int maxcount = 0;
     bool attr = false;
     hipStream_t pstream = nullptr;                  // stage 1: the panel factorisations run ahead on it
@@ -721,7 +817,8 @@ struct Ht2Workspace {
         if (!attr) {
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_geng_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_m1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_m2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_left_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_LEFT_LDS));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_wy_right_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WY_RIGHT_LDS));
@@ -759,11 +856,11 @@ struct Ht2Workspace {
         alloc(HV, refl * R2); alloc(HT, refl); alloc(GV, refl * R2); alloc(GT, refl);
         alloc(Vb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2); alloc(VTb, (size_t)2 * ht2_tstride(n) * 2 * R2 * R2);
         maxcount = n / (LAG * R2 - 1) + 4;
-        alloc(Bcopy, (size_t)maxcount * R2 * R2);
+        alloc(gstate, (size_t)maxcount * GEN_STATE);
     }
     void release()
     {
-        double **all[] = {&V, &VT, &HV, &HT, &GV, &GT, &Vb, &VTb, &Bcopy};
+        double **all[] = {&V, &VT, &HV, &HT, &GV, &GT, &Vb, &VTb, &gstate};
         for (double **p : all) if (*p) { SN_HIP_CHECK(hipFree(*p)); *p = nullptr; }
         n = 0;
     }
@@ -943,9 +1040,8 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     if (between) SN_HIP_CHECK(hipEventRecord(between, s));
     // ---- stage 2 -----------------------------------------------------------------------------------------------
     // The steps of a wavefront are independent; a step depends on its own sweep's previous step and on OLDER sweeps'
-    // steps of the wavefronts before.  Three launches a wavefront on `s`: the left reflectors (one small workgroup a
-    // step), the opposite reflectors (75 us of latency, one workgroup a step) under the left application, the right
-    // application.  (Dealing the sweeps of a wavefront to 2-4 streams so that one chain's generation hides under the
+    // steps of the wavefronts before.  Three launches a wavefront on `s` (the schedule is stated above the loop below).
+    // (Dealing the sweeps of a wavefront to 2-4 streams so that one chain's generation hides under the
     // others' applications was correct and 2.5 x slower -- every hand-over between streams is 11 us of a loop the
     // host already bounds; round 5; removed.)
     int opened = 0, closed = 0;          // groups whose slot is claimed / whose blocks are on their way to Q, Z and the top rows
@@ -969,22 +1065,67 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         }
         if (sq != s) SN_HIP_CHECK(hipEventRecord(ws.applied[slot], sq));
     };
+    // Three launches a wavefront, all on `s` (round 6):
+    //   M2(tau)   = { second halves of the generations of tau | left(tau) }      left(tau): the left reflectors WITHOUT
+    //                                                                             the steps' own diagonal blocks
+    //   near(tau) = H on the steps' own diagonal blocks, then the near parts of the right applications: the rows from
+    //               p - (r - 1) on -- everything the next wavefront's reflectors are generated from
+    //   M1(tau)   = { first halves of the generations of tau' | far(tau) }       tau': the next non-empty wavefront;
+    //                                                                             far(tau): the rows above p - (r - 1)
+    // so that the 75 us of a generation pass beside BOTH HBM-bound applications -- a wavefront was genh + max(gen, left)
+    // + right, it is max(gen / 2, far) + max(gen / 2, left) + near.  What makes it legal: the first half of gen(tau')
+    // reads and writes nothing that far(tau) touches (it reads A(p + r : p + 2r, p) and B(I', I'), whose last column
+    // B(p - r + 1 : p + 1, p) is the older neighbour's near part), and a step's H on its own blocks A(I, I), B(I, I)
+    // can wait for near(tau) because no other operation of the wavefront touches them.  scratch/ht2_overlap.py runs
+    // this order in numpy (with the negative controls: fewer than r - 1 rows above the block in the near part; the own
+    // blocks left with left(tau)) and checks the entry sets of the operations that share a launch for overlaps.
+    // (Tried first: the HBM-bound parts on a second stream, the generation whole on the chain -- correct, and slower
+    // than before: every cross-stream hand-over is 10-14 us even when the event has long been signalled, a record
+    // between two launches 7 us, and a wavefront needs four of them; stage 2 at n = 8000 2.35 -> 2.62 s.)
+    std::vector<int> taus;                              // the non-empty wavefronts
     for (int tau_idx = 0;; tau_idx++) {
         int jlo, count;
         if (!wavefront(tau_idx, jlo, count)) { if (tau_idx / LAG >= n - 3) break; else continue; }
-        int const jhi = jlo + count - 1;
+        taus.push_back(tau_idx);
+    }
+    auto wave_of = [&](int tau_idx) { int jlo = 0, count = 0; wavefront(tau_idx, jlo, count); return Wave2{n, tau_idx, jlo, count, tstride, nslot}; };
+    auto open_slots = [&](Wave2 const &w) {            // before the first launch that writes reflectors of w
+        int const jhi = w.jlo + w.count - 1;
         for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
             if (opened >= nslot && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.applied[opened % nslot], 0));
-        Wave2 const w{n, tau_idx, jlo, count, tstride, nslot};
-        int const nchunk = divceil(n, LEFT_CHUNK);
-        hipLaunchKernelGGL(ht2_genh_kernel, dim3(count), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT, ws.Bcopy);
-        hipLaunchKernelGGL(ht2_geng_left_kernel, dim3(count + count * 2 * nchunk), dim3(QT), GEN_LDS_BYTES, s, w, nchunk, A, lda, B, ldb,
-            ws.HV, ws.HT, ws.GV, ws.GT, ws.Bcopy);
-        // (the oldest sweep of the wavefront has the smallest top: its row tiles bound the grid)
-        int const base = ((jlo / GS) * GS + 1) & ~15;
-        hipLaunchKernelGGL(ht2_apply_right_kernel, dim3(divceil(n - base, 64), count, 2), dim3(256), 0, s, w,
-            RightTargets{{B, A, nullptr}, {ldb, lda, 0}, {1, 2, 0}}, n, ws.GV, ws.GT);
+    };
+    Wave2 const none{n, 0, 0, 0, tstride, nslot};
+    int const nchunk = divceil(n, LEFT_CHUNK) + 1;
+    auto split_of = [&](Wave2 const &w) {              // (the bytes the left applications of the wavefront move)
+        double bytes = 0.0;
+        for (int k = 0; k < w.count; k++) {
+            int const j = w.jlo + k, t = w.tau_idx - LAG * j, p = j + 1 + t * R2;
+            if (t < 0 || j > n - 3 || p > n - 2) continue;
+            bytes += 16.0 * std::min(R2, n - p) * (2.0 * (n - p) - R2);
+        }
+        return bytes / LEFT_BYTES_PER_US >= GEN_HIDE_US ? 0 : GEN_SPLIT;
+    };
+    int split = GEN_SPLIT;
+    if (!taus.empty()) {
+        Wave2 const w0 = wave_of(taus[0]);
+        open_slots(w0);
+        split = split_of(w0);
+        hipLaunchKernelGGL(ht2_m1_kernel, dim3(w0.count), dim3(QT), GEN_LDS_BYTES, s, w0, split, none, 1, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT, ws.gstate);
+    }
+    for (size_t it = 0; it < taus.size(); it++) {
+        int const tau_idx = taus[it];
+        Wave2 const w = wave_of(tau_idx);
+        hipLaunchKernelGGL(ht2_m2_kernel, dim3(w.count + w.count * 2 * nchunk), dim3(QT), GEN_LDS_BYTES, s, w, split, nchunk, A, lda, B, ldb,
+            ws.HV, ws.HT, ws.GV, ws.GT, ws.gstate);
+        hipLaunchKernelGGL(ht2_near_kernel, dim3(3, w.count, 2), dim3(256), 0, s, w, A, lda, B, ldb, ws.HV, ws.HT, ws.GV, ws.GT);
         for (; closed < ngroups && last_wave(closed) <= tau_idx; closed++) close_group(closed);
+        Wave2 const wn = it + 1 < taus.size() ? wave_of(taus[it + 1]) : none;
+        if (wn.count > 0) open_slots(wn);
+        // (the oldest sweep of the wavefront has the smallest top: its row tiles bound the grid)
+        int const base = ((w.jlo / GS) * GS + 1) & ~15, ntile4 = std::max(1, divceil(divceil(n - base, 64), 4));
+        split = wn.count > 0 ? split_of(wn) : GEN_SPLIT;
+        hipLaunchKernelGGL(ht2_m1_kernel, dim3(wn.count + w.count * 2 * ntile4), dim3(QT), GEN_LDS_BYTES, s, wn, split, w, ntile4, A, lda, B, ldb,
+            ws.HV, ws.HT, ws.GV, ws.GT, ws.gstate);
     }
     for (; closed < ngroups; closed++) close_group(closed);
     if (sq != s) {
