@@ -229,9 +229,13 @@ def two_stage_roofline(n, st, traffic=None):
     stage2_s = (st["rotation_ms"] - st["stage1_ms"]) / 1e3
     return {"bound": "hbm", "achieved": nbytes / stage2_s / 1e9, "peak": 8000.0, "unit": "GB/s",
             "frac": nbytes / stage2_s / 1e9 / 8000.0, "traffic": traffic,
-            "kernel": "ht2_geng_left_kernel (left application) + ht2_apply_right_kernel + the deferred rows in "
-                      "ht2_wy_right_kernel over stage 2 (%.2f s, %.1f TB algorithmic of which %.2f TB deferred; "
-                      "rounds 1-5 applied everything at once: %.1f TB)"
+            "kernel": "the three launches of a stage-2 wavefront -- ht2_m2_kernel (left application beside the second "
+                      "half of the generation), ht2_near_kernel, ht2_m1_kernel (far part of the right application "
+                      "beside the first half of the next generation) -- + the deferred rows in ht2_wy_right_kernel "
+                      "(%.2f s, %.1f TB algorithmic of which %.2f TB deferred; rounds 1-5 applied everything at once: "
+                      "%.1f TB); the 512-byte column pieces of the left application start on no 128-byte boundary: "
+                      "a stand-alone copy of the pattern moves 3.6 TB/s where an in-place stream moves 4.7 "
+                      "(profiles/r6_ht2_apply_patterns.txt)"
                       % (stage2_s, nbytes / 1e12, later / 1e12,
                          16.0 * float(((left + ln * (np.minimum(p1 + r, n) + p1)) * live).sum()) / 1e12)}
 
