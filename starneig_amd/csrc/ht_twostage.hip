@@ -245,7 +245,7 @@ __device__ void lds_vtt(double const *V, int ldv, double const *T, OUT out)
 
 // Stage 1, left: QR of the m x nb block X = A(i0:i0+m, jc:jc+nb) (m <= 2 r, nb <= r); R back in place with
 // exact zeros below it, V (m x nb, unit lower trapezoidal) and V T^T (m x nb) out, leading dimension ldv both.
-__global__ __launch_bounds__(QT) void ht2_panel_qr_kernel(double *__restrict__ X, int ldx, int m, int nb,
+__device__ void panel_qr_body(double *__restrict__ X, int ldx, int m, int nb,
     double *__restrict__ V, double *__restrict__ VT, int ldv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(QT) void ht2_panel_qr_kernel(double *__restrict__ X
 // Stage 1, right: the mb x m block Mb = B(i1-mb:i1, i0:i1) (mb <= r, m <= 2 r) becomes [0 R] (R mb x mb upper
 // triangular) under G = I - V T V^T from the right: QR of the flipped transpose, flip(Mb^T) = Qr R, G = flip Qr flip.
 // V, V T^T: m x mb (rows = columns of the block).
-__global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int ldb, int mb, int m,
+__device__ void rq_body(double *__restrict__ Mb, int ldb, int mb, int m,
     double *__restrict__ V, double *__restrict__ VT, int ldv)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -293,6 +293,18 @@ __global__ __launch_bounds__(QT) void ht2_rq_kernel(double *__restrict__ Mb, int
     lds_vtt(P, LDP, Tl, [&](int row, int c, double x) { if (row < m && c < mb) VT[(size_t)c * ldv + (m - 1 - row)] = x; });
 }
 constexpr int PANEL_LDS_BYTES = (R2 * LDP + 2 * R2 * R2 + R2 * R2 / 4 + 2 * R2 + 16) * 8;
+// Up to two single-workgroup factorisations in one launch (blockIdx.x): the RQ factorisation of a step and the panel
+// QR factorisation of the NEXT step of the block column, which depends on nothing the chain of `s` does in between --
+// both are ~92 us of latency on one CU each, so the second one is free, and the factors reach their consumers by stream
+// order (round 6; before, the panel factorisations ran ahead on a stream of their own and every step paid a
+// cross-stream wait, 10-14 us even when the event had long been signalled).
+struct FactorJob { int kind; double *X; int ld, a, b; double *V, *VT; };          // kind 0: none, 1: panel QR (m = a, nb = b), 2: RQ (mb = a, m = b)
+__global__ __launch_bounds__(QT) void ht2_factor_kernel(FactorJob j0, FactorJob j1)
+{
+    FactorJob const &j = blockIdx.x == 0 ? j0 : j1;
+    if (j.kind == 1) panel_qr_body(j.X, j.ld, j.a, j.b, j.V, j.VT, 2 * R2);
+    else if (j.kind == 2) rq_body(j.X, j.ld, j.a, j.b, j.V, j.VT, 2 * R2);
+}
 
 // ---- stage 2 --------------------------------------------------------------------------------------------------
 // wavefront tau_idx: sweeps jlo .. jlo + count - 1, position t = tau_idx - LAG j.  The reflectors of a step are kept
@@ -815,8 +827,7 @@ struct Ht2Workspace {
     void ensure(int n_)
     {
         if (!attr) {
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_panel_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
-            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
+            SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_m1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_m2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
             SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht2_group_wy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_LDS_BYTES));
@@ -952,16 +963,31 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         }
     }
     // ---- stage 1 -----------------------------------------------------------------------------------------------
-    // Three streams.  The QR factorisations of a block column's panels touch the panel's columns only, and nothing
-    // else does until the next block column: they run ahead on `sp`, a ring of factor slots (V, V T^T) between them
-    // and their consumers -- `s` (the trailing columns of A and the rows of B in one launch; then the RQ
-    // factorisation of the filled block of B and its application to B and A, from a second ring) and `sq` (Q, Z).
-    // The host is the bottleneck here, so the calls are counted: a consumer tells the producer of a ring that slots
-    // are free again once per EPOCH steps, not per step (two events per ring and consumer, alternating).
-    hipStream_t const sp = ws.pstream;
+    // Two streams.  `s`: per step the application of the panel's left factor (the trailing columns of A and the rows of
+    // B in one launch), the RQ factorisation of the filled block of B -- with the NEXT step's panel QR factorisation
+    // as a second workgroup of the same launch (ht2_factor_kernel): it touches the panel's columns only, and nothing
+    // else does until the next block column --, the application of the right factor to B and A.  `sq`: Q and Z, from two
+    // rings of factor slots (V, V T^T); it tells `s` that slots are free again once per EPOCH steps, not per step
+    // (two events per ring, alternating): the host's calls are counted here.
     bool const side = sq != s;
     long lcount = 0, rcount = 0;
     WyJob pendq{}; int pendq_slot = 0; long pendq_count = 0; bool have_pendq = false;   // a left factor waiting for its turn on Q
+    // The application of a step's factors to Q and Z is handed to `sq` when the NEXT factorisation is launched, not
+    // when its own is through: it then runs beside 92 us of latency on one CU instead of beside the HBM-bound
+    // applications of the chain (which took 23 + 30 us next to it, 23 + 18 without; round 6).
+    struct PendZ { bool have; int sl; long rc; WyJob z; bool with_q; WyJob q; long qcount; };
+    PendZ pendz{false, 0, 0, WyJob{}, false, WyJob{}, 0};
+    auto flush_z = [&]() {
+        if (!pendz.have) return;
+        if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready_r[pendz.sl], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[pendz.sl], 0)); }
+        if (pendz.with_q) {
+            hipLaunchKernelGGL(ht2_wy_right2_kernel, dim3(divceil(n, WY_SLAB), 2), dim3(WY_T), WY_RIGHT_LDS, sq, pendz.q, pendz.z);
+            if (side && pendz.qcount % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used[(pendz.qcount / (RING / 2)) % 2], sq));
+        } else
+            wy_right(sq, pendz.z.V, pendz.z.VT, pendz.z.m, pendz.z.k, pendz.z.X, pendz.z.ld, pendz.z.nrows);
+        if (side && pendz.rc % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used_r[(pendz.rc / (RING / 2)) % 2], sq));
+        pendz.have = false;
+    };
     constexpr int EPOCH = RING / 2;
     // consumer side: after step i of a ring; producer side: before step L of that ring
     auto epoch_record = [&](hipEvent_t *ev, long i, hipStream_t st) { if (i % EPOCH == EPOCH - 1) SN_HIP_CHECK(hipEventRecord(ev[(i / EPOCH) % 2], st)); };
@@ -970,24 +996,30 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         int const nb = std::min(r, n - jc), top = jc + r;
         std::vector<int> starts;
         for (int i = top; i < n; i += r) starts.push_back(i);
-        // the panel's columns are final once `s` is through the previous block column
-        SN_HIP_CHECK(hipEventRecord(ws.column, s));
-        SN_HIP_CHECK(hipStreamWaitEvent(sp, ws.column, 0));
+        int const K = (int)starts.size();
+        struct LeftJob { int i0, i1; };
+        std::vector<LeftJob> lefts;                     // bottom up; all but a lone one (K == 1) are followed by a right step
+        for (int k = K - 1; k >= 1; k--) lefts.push_back({starts[k - 1], std::min(starts[k] + r, n)});
+        if (K == 1 && n - top > 1) lefts.push_back({top, n});
+        // the panel QR of left step q of this block column, into slot (lcount + q - done) % RING
+        long const lbase = lcount;
+        auto panel_job = [&](int q) {
+            long const L = lbase + q;
+            int const sl = (int)(L % RING);
+            if (side && Q) epoch_wait(ws.used, L, s);             // `sq` is through with the slot
+            return FactorJob{1, A + (size_t)jc * lda + lefts[q].i0, lda, lefts[q].i1 - lefts[q].i0, nb,
+                ws.V + (size_t)sl * 2 * r * r, ws.VT + (size_t)sl * 2 * r * r};
+        };
         auto flush_q = [&]() {
             if (!have_pendq) return;
-            if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0));
+            if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready[pendq_slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0)); }
             wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
             if (side) epoch_record(ws.used, pendq_count, sq);
             have_pendq = false;
         };
-        auto left_step = [&](int i0, int i1) {
+        auto left_step = [&](int i0, int i1) {              // (its factor is in its slot: an earlier launch of `s`)
             int const m = i1 - i0, k = nb, sl = (int)(lcount % RING);
             double *V = ws.V + (size_t)sl * 2 * r * r, *VT = ws.VT + (size_t)sl * 2 * r * r;
-            epoch_wait(ws.used_s, lcount, sp);
-            if (side && Q) epoch_wait(ws.used, lcount, sp);
-            hipLaunchKernelGGL(ht2_panel_qr_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, sp, A + (size_t)jc * lda + i0, lda, m, nb, V, VT, 2 * r);
-            SN_HIP_CHECK(hipEventRecord(ws.ready[sl], sp));
-            SN_HIP_CHECK(hipStreamWaitEvent(s, ws.ready[sl], 0));
             wy_left(s, V, VT, m, k, A + (size_t)(jc + nb) * lda + i0, lda, n - jc - nb, B + (size_t)i0 * ldb + i0, ldb, n - i0);
             if (Q) {
                 // the application to Q waits for the right step that follows (one launch for Q and Z); a left step
@@ -996,44 +1028,41 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
                 pendq = WyJob{V, VT, m, k, Q + (size_t)i0 * ldq, ldq, n};
                 pendq_slot = sl; pendq_count = lcount; have_pendq = true;
             }
-            epoch_record(ws.used_s, lcount, s);
             lcount++;
         };
-        auto right_step = [&](int i0, int i1, int mb) {
+        auto right_step = [&](int i0, int i1, int mb, FactorJob next_panel) {
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
             int const m = i1 - i0, sl = (int)(rcount % RING);
             double *V = ws.V + (size_t)(RING + sl) * 2 * r * r, *VT = ws.VT + (size_t)(RING + sl) * 2 * r * r;
+            flush_z();                                      // the previous step's Q / Z launch: beside THIS factorisation
             if (side && Z) epoch_wait(ws.used_r, rcount, s);
-            hipLaunchKernelGGL(ht2_rq_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT, 2 * r);
-            if (Z && side) SN_HIP_CHECK(hipEventRecord(ws.ready_r[sl], s));
+            hipLaunchKernelGGL(ht2_factor_kernel, dim3(next_panel.kind ? 2 : 1), dim3(QT), PANEL_LDS_BYTES, s,
+                FactorJob{2, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT}, next_panel);
             wy_right(s, V, VT, m, mb, A + (size_t)i0 * lda, lda, n, B + (size_t)i0 * ldb, ldb, i1 - mb);
             if (Z) {
-                // (ready_r is recorded on `s` behind the wait for the left factor of this step: it covers both)
-                if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[sl], 0));
-                if (have_pendq && mb > 0) {
-                    hipLaunchKernelGGL(ht2_wy_right2_kernel, dim3(divceil(n, WY_SLAB), 2), dim3(WY_T), WY_RIGHT_LDS, sq,
-                        pendq, WyJob{V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n});
-                    if (side) epoch_record(ws.used, pendq_count, sq);
-                    have_pendq = false;
-                } else
-                    wy_right(sq, V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n);
-                if (side) epoch_record(ws.used_r, rcount, sq);
+                pendz = PendZ{true, sl, rcount, WyJob{V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n}, have_pendq && mb > 0, pendq, pendq_count};
+                if (pendz.with_q) have_pendq = false;
             }
             rcount++;
         };
-        int const K = (int)starts.size();
-        for (int k = K - 1; k >= 1; k--) {
-            int const i0 = starts[k - 1], i1 = std::min(starts[k] + r, n);
-            left_step(i0, i1);
-            int const mb = i1 - (i0 + r);
-            if (mb > 0) right_step(i0, i1, mb);
+        FactorJob const none{0, nullptr, 0, 0, 0, nullptr, nullptr};
+        if (!lefts.empty()) {
+            // (the panel's columns are final: `s` is through the previous block column)
+            FactorJob const first = panel_job(0);
+            hipLaunchKernelGGL(ht2_factor_kernel, dim3(1), dim3(QT), PANEL_LDS_BYTES, s, first, none);
         }
-        if (K == 1 && n - top > 1) left_step(top, n);
+        for (int q = 0; q < (int)lefts.size(); q++) {
+            int const i0 = lefts[q].i0, i1 = lefts[q].i1;
+            left_step(i0, i1);
+            if (K == 1) break;                              // the lone left step: the right step below is the block column's last
+            right_step(i0, i1, i1 - (i0 + r), q + 1 < (int)lefts.size() ? panel_job(q + 1) : none);
+        }
         int const i1 = std::min(top + r, n);
-        if (i1 - top > 1) right_step(top, i1, i1 - top);
+        if (i1 - top > 1) right_step(top, i1, i1 - top, none);
     }
+    flush_z();
     if (have_pendq) {       // (the last left factor of stage 1, if no right step followed it)
-        if (side) SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0));
+        if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready[pendq_slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0)); }
         wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
         have_pendq = false;
     }
