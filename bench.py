@@ -114,7 +114,7 @@ def run_gep_chain(S, n):
     import torch
     out = None
     first = None
-    for m in (1000, 1600, n, n):       # (warm-ups: the rotation path, the two-stage path from n = 1500, and the
+    for m in (1000, 1600, n, n):       # (warm-ups: the rotation path, the two-stage path from n = 1100, and the
                                        # size itself -- the first call at a size allocates the workspaces)
         tA, tB = S.device_matrix(m), S.device_matrix(m)
         S.lcg_fill_device(tA, m, m, seed=2019); S.lcg_fill_device(tB, m, m, seed=77)

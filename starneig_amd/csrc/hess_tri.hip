@@ -1005,7 +1005,7 @@ int hessenberg_triangular_device(hipStream_t caller, int n, double *dA, int ldA,
         SN_HIP_CHECK(hipFuncSetAttribute((const void *)ht_chain_kernel<HG, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_DOUBLES(HG) * 8));
         attr_set = true;
     }
-    // From n = 1500 on the two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps (twice
+    // From n = 1100 on (tuning.h: ht2_min_n) the two-stage Householder reduction (ht_twostage.hip) instead of the rotation sweeps (twice
     // as fast at n = 8000; SN_HT_TWOSTAGE=0 / 1 forces either) -- DESIGN.md section 4d has the measurements
     int const two_stage = ht_two_stage_fits(n) && (tuning().ht_two_stage > 0 || (tuning().ht_two_stage < 0 && n >= tuning().ht2_min_n));
     int two_stage_rc = 0;

@@ -40,7 +40,7 @@ struct Tuning {
     int gemm_kchunk = 0;            // SN_GEMM_KCHUNK: longest k of one split-K slice (0 = the built-in policy)
     int ht_two_stage = -1;          // SN_HT_TWOSTAGE: the two-stage Householder path of the Hessenberg-triangular reduction (ht_twostage.hip):
                                     // 1 always, 0 never, unset: from n = ht2_min_n on
-    int ht2_min_n = 1500;           // SN_HT2_MIN_N: (the rotation path is the faster one up to n ~ 1000)
+    int ht2_min_n = 1100;           // SN_HT2_MIN_N: (the rotation path is the faster one up to n ~ 1000: profiles/r6_ht_crossover.txt; 1500 until the two-stage path's round-6 work)
     // QZ
     bool gep_serial = false;        // SN_GEP_SERIAL
     int gep_reuse = 0;              // SN_GEP_REUSE

@@ -95,8 +95,8 @@ def test_device_api_residuals(node, n):
     tQ = node.device_matrix(n); node.set_matrix_device(tQ, n, n, 0.0, 1.0)
     tZ = node.device_matrix(n); node.set_matrix_device(tZ, n, n, 0.0, 1.0)
     rc, st = node.hessenberg_triangular_device(tA, tB, tQ, tZ, n=n)
-    # from n = 1500 on the two-stage Householder path (csrc/ht_twostage.hip) takes over from the rotations
-    assert rc == 0 and st["two_stage"] == (n >= 1500)
+    # from n = 1100 on the two-stage Householder path (csrc/ht_twostage.hip) takes over from the rotations
+    assert rc == 0 and st["two_stage"] == (n >= 1100)
     if not st["two_stage"]:
         assert st["rotations"] == 2.0 * sum(n - j - 2 for j in range(n - 2))
     tA0, tB0 = to_device(A0), to_device(B0)

@@ -1,6 +1,6 @@
 """GPU: the two-stage Householder reduction to Hessenberg-triangular form (csrc/ht_twostage.hip): stage 1 to
 band form by blocked QR / RQ factorisations, stage 2 a chase of Householder bulges with opposite reflectors.  It is
-the product path from n = 1500 on (1.4x the rotation path at n = 2500, 2x at n = 8000); the
+the product path from n = 1100 on (1.4x the rotation path at n = 2500, 2x at n = 8000); the
 switch SN_HT_TWOSTAGE=1 (read once per process -> child processes) forces it at every size.  Asserted: a correct,
 backward stable reduction -- exact structure, the reference's residual / orthogonality hooks -- at sizes around
 every block boundary, also on a singular B, and QZ on its output."""
@@ -91,7 +91,7 @@ print("OK")
 
 
 def test_default_path_by_size(tmp_path):
-    """without any switch: rotations below n = 1500, the two-stage path from there on"""
+    """without any switch: rotations below n = 1100, the two-stage path from there on"""
     code = r"""
 import os, sys
 import torch
@@ -99,11 +99,11 @@ torch.cuda.set_device(0); torch.zeros(1, device="cuda")
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import starneig_amd as S
 S.node_init(1, 1, S.NO_MESSAGES)
-for n in (1499, 1500):
+for n in (1099, 1100):
     tA, tB = S.device_matrix(n), S.device_matrix(n)
     S.lcg_fill_device(tA, n, n, seed=2019); S.lcg_fill_device(tB, n, n, seed=77)
     rc, st = S.hessenberg_triangular_device(tA, tB, None, None, n=n)
-    assert rc == 0 and st["two_stage"] == (n >= 1500), (n, st)
+    assert rc == 0 and st["two_stage"] == (n >= 1100), (n, st)
 S.node_finalize()
 print("OK")
 """
@@ -191,7 +191,7 @@ print("OK")
 
 @pytest.mark.parametrize("two_stage", [1, 0])
 def test_reduce_of_a_general_pencil_against_lapack(two_stage):
-    """the two-stage path (the default from n = 1500) against the oracle's pins on a GENERAL
+    """the two-stage path (the default from n = 1100) against the oracle's pins on a GENERAL
     pencil -- n = 2000, the test driver's generalized Hessenberg input: singular values of T against LAPACK's of B,
     Hessenberg-triangular + QZ eigenvalues against LAPACK dggev's (committed fixture, tolerance from LAPACK's own
     spread and the measured sensitivity), and a rank-deficient B at n = 1600 through starneig_GEP_SM_Reduce: the count

@@ -3,7 +3,10 @@
 wait for `ready`, read the slot, and tell the producer that slots are free again only once per EPOCH = RING / 2 steps,
 through two alternating events (the host is the bottleneck of that loop: every runtime call counts).  HIP semantics:
 a wait refers to the most recent record of the event that was ENQUEUED before it.  Under every interleaving of the
-streams a consumer must find in a slot what its step put there."""
+streams a consumer must find in a slot what its step put there.
+Round 6: the producer of both rings is the chain's stream itself (the panel QR of the next step is the second workgroup
+of a step's RQ launch) and the consumer `sq` gets a step's hand-over -- the `ready` record and its own wait and launch --
+one step LATE, when the next factorisation is launched (`flush_z`): `defer=True` below."""
 import random
 
 import pytest
@@ -11,7 +14,7 @@ import pytest
 RING, EPOCH = 8, 4
 
 
-def enqueue(nsteps, consumers):
+def enqueue(nsteps, consumers, defer=False):
     """the host loop: per-stream op lists; ops are ("wait", record_id | None), ("write", L), ("read", L), ("record", id)"""
     streams = {"P": []}
     for c in consumers:
@@ -27,18 +30,25 @@ def enqueue(nsteps, consumers):
     def wait(stream, ev):
         streams[stream].append(("wait", last.get(ev)))
 
-    for L in range(nsteps):
-        sl = L % RING
-        if L >= RING and L % EPOCH == 0:                     # epoch_wait(used_*, L, producer)
-            for c in consumers:
-                wait("P", (c, (L // EPOCH) % 2))
-        streams["P"].append(("write", L))
-        record("P", ("ready", sl))
+    def hand_over(L):
+        record("P", ("ready", L % RING))
         for c in consumers:
-            wait(c, ("ready", sl))
+            wait(c, ("ready", L % RING))
             streams[c].append(("read", L))
             if L % EPOCH == EPOCH - 1:                       # epoch_record(used_*, L, consumer)
                 record(c, (c, (L // EPOCH) % 2))
+
+    for L in range(nsteps):
+        if L >= RING and L % EPOCH == 0:                     # epoch_wait(used_*, L, producer)
+            for c in consumers:
+                wait("P", (c, (L // EPOCH) % 2))
+        if defer and L > 0:
+            hand_over(L - 1)                                 # flush_z: before the launch that writes step L's slot
+        streams["P"].append(("write", L))
+        if not defer:
+            hand_over(L)
+    if defer and nsteps > 0:
+        hand_over(nsteps - 1)
     return streams
 
 
@@ -63,11 +73,12 @@ def run(streams, rng):
         pos[k] += 1
 
 
+@pytest.mark.parametrize("defer", [False, True])
 @pytest.mark.parametrize("consumers", [("s",), ("s", "sq")])
-def test_ring_slots_are_never_overwritten_before_they_are_read(consumers):
+def test_ring_slots_are_never_overwritten_before_they_are_read(consumers, defer):
     rng = random.Random(5)
     for trial in range(300):
-        run(enqueue(rng.choice([1, 7, 8, 9, 23, 64]), consumers), rng)
+        run(enqueue(rng.choice([1, 7, 8, 9, 23, 64]), consumers, defer), rng)
 
 
 def test_the_model_notices_a_missing_wait():
