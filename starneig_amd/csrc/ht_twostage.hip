@@ -975,18 +975,23 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     // The application of a step's factors to Q and Z is handed to `sq` when the NEXT factorisation is launched, not
     // when its own is through: it then runs beside 92 us of latency on one CU instead of beside the HBM-bound
     // applications of the chain (which took 23 + 30 us next to it, 23 + 18 without; round 6).
-    struct PendZ { bool have; int sl; long rc; WyJob z; bool with_q; WyJob q; long qcount; };
-    PendZ pendz{false, 0, 0, WyJob{}, false, WyJob{}, 0};
-    auto flush_z = [&]() {
-        if (!pendz.have) return;
-        if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready_r[pendz.sl], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[pendz.sl], 0)); }
-        if (pendz.with_q) {
-            hipLaunchKernelGGL(ht2_wy_right2_kernel, dim3(divceil(n, WY_SLAB), 2), dim3(WY_T), WY_RIGHT_LDS, sq, pendz.q, pendz.z);
-            if (side && pendz.qcount % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used[(pendz.qcount / (RING / 2)) % 2], sq));
-        } else
-            wy_right(sq, pendz.z.V, pendz.z.VT, pendz.z.m, pendz.z.k, pendz.z.X, pendz.z.ld, pendz.z.nrows);
-        if (side && pendz.rc % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used_r[(pendz.rc / (RING / 2)) % 2], sq));
-        pendz.have = false;
+    // ... and ZBATCH steps share one hand-over (one event record on the chain, 7 us, instead of one a step; `sq` lags by
+    // up to ZBATCH steps behind, the rings hold RING = 8: tests/test_ht_ring_epochs.py runs the protocol).
+    struct PendZ { int sl; long rc; WyJob z; bool with_q; WyJob q; long qcount; };
+    constexpr int ZBATCH = 3;
+    std::vector<PendZ> pendz;
+    auto flush_z = [&](bool all) {
+        if (pendz.empty() || (!all && (int)pendz.size() < ZBATCH)) return;
+        if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready_r[pendz.back().sl], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready_r[pendz.back().sl], 0)); }
+        for (PendZ const &pz : pendz) {
+            if (pz.with_q) {
+                hipLaunchKernelGGL(ht2_wy_right2_kernel, dim3(divceil(n, WY_SLAB), 2), dim3(WY_T), WY_RIGHT_LDS, sq, pz.q, pz.z);
+                if (side && pz.qcount % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used[(pz.qcount / (RING / 2)) % 2], sq));
+            } else
+                wy_right(sq, pz.z.V, pz.z.VT, pz.z.m, pz.z.k, pz.z.X, pz.z.ld, pz.z.nrows);
+            if (side && pz.rc % (RING / 2) == RING / 2 - 1) SN_HIP_CHECK(hipEventRecord(ws.used_r[(pz.rc / (RING / 2)) % 2], sq));
+        }
+        pendz.clear();
     };
     constexpr int EPOCH = RING / 2;
     // consumer side: after step i of a ring; producer side: before step L of that ring
@@ -1012,6 +1017,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         };
         auto flush_q = [&]() {
             if (!have_pendq) return;
+            flush_z(true);                                  // (the order of the applications to Q)
             if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready[pendq_slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0)); }
             wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
             if (side) epoch_record(ws.used, pendq_count, sq);
@@ -1034,14 +1040,14 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
             // the bottom mb rows of the block B(i0:i1, i0:i1) become [0 R]
             int const m = i1 - i0, sl = (int)(rcount % RING);
             double *V = ws.V + (size_t)(RING + sl) * 2 * r * r, *VT = ws.VT + (size_t)(RING + sl) * 2 * r * r;
-            flush_z();                                      // the previous step's Q / Z launch: beside THIS factorisation
+            flush_z(false);                                 // earlier steps' Q / Z launches: beside THIS factorisation
             if (side && Z) epoch_wait(ws.used_r, rcount, s);
             hipLaunchKernelGGL(ht2_factor_kernel, dim3(next_panel.kind ? 2 : 1), dim3(QT), PANEL_LDS_BYTES, s,
                 FactorJob{2, B + (size_t)i0 * ldb + (i1 - mb), ldb, mb, m, V, VT}, next_panel);
             wy_right(s, V, VT, m, mb, A + (size_t)i0 * lda, lda, n, B + (size_t)i0 * ldb, ldb, i1 - mb);
             if (Z) {
-                pendz = PendZ{true, sl, rcount, WyJob{V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n}, have_pendq && mb > 0, pendq, pendq_count};
-                if (pendz.with_q) have_pendq = false;
+                pendz.push_back(PendZ{sl, rcount, WyJob{V, VT, m, mb, Z + (size_t)i0 * ldz, ldz, n}, have_pendq && mb > 0, pendq, pendq_count});
+                if (pendz.back().with_q) have_pendq = false;
             }
             rcount++;
         };
@@ -1060,7 +1066,7 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
         int const i1 = std::min(top + r, n);
         if (i1 - top > 1) right_step(top, i1, i1 - top, none);
     }
-    flush_z();
+    flush_z(true);
     if (have_pendq) {       // (the last left factor of stage 1, if no right step followed it)
         if (side) { SN_HIP_CHECK(hipEventRecord(ws.ready[pendq_slot], s)); SN_HIP_CHECK(hipStreamWaitEvent(sq, ws.ready[pendq_slot], 0)); }
         wy_right(sq, pendq.V, pendq.VT, pendq.m, pendq.k, pendq.X, pendq.ld, pendq.nrows);
