@@ -808,11 +808,14 @@ __global__ __launch_bounds__(WY_T) void ht2_wy_right2_kernel(WyJob j0, WyJob j1)
 }
 
 constexpr int RING = 8;             // stage 1: factor slots in flight between the critical stream and the stream of Q and Z
-constexpr int MAXSLOT = 16;         // stage 2: groups of sweeps whose reflectors are kept at a time
+constexpr int MAXSLOT = 256;        // stage 2: groups of sweeps whose reflectors are kept at a time
+constexpr int EXTRASLOT = 40;        // ... beyond what the chase itself needs: a group's reflectors stay until the side stream has applied them to Q, Z and
+                                    // the top rows, and with the bare minimum (4 at n = 12000) the chase waited for that stream (stage 2 6.07 -> 5.95 s)
 inline int ht2_tstride(int n) { return (n - 3) / R2 + 1; }
 // a group is in the chase for LAG (GS - 1) + tstride wavefronts, the next one starts LAG GS wavefronts after it; one
 // more slot for the group whose blocks the second stream is still applying
-inline int ht2_nslot(int n) { return std::min(MAXSLOT, (ht2_tstride(n) + LAG * GS - LAG) / (LAG * GS) + 2); }
+inline int ht2_need_slots(int n) { return (ht2_tstride(n) + LAG * GS - LAG) / (LAG * GS) + 2; }
+inline int ht2_nslot(int n) { return std::min(MAXSLOT, ht2_need_slots(n) + EXTRASLOT); }
 struct Ht2Workspace {
     int n = 0;
     double *V = nullptr, *VT = nullptr;             // stage 1: two rings (QR, RQ) of RING slots of V and V T^T (2r x r each)
@@ -920,10 +923,10 @@ void wy_right3(hipStream_t s, double const *V, double const *VT, int m, int k, W
 void ht_two_stage_release_workspace() { g_ht2.release(); }
 
 // Can the two-stage path take this n?  (The slots of the reflector store bound the groups of sweeps in flight:
-// MAXSLOT = 16 covers n < ~100 000; the caller falls back to the rotation path otherwise.)
+// MAXSLOT = 256 covers every n that fits the memory; the caller falls back to the rotation path otherwise.)
 bool ht_two_stage_fits(int n)
 {
-    return n >= 3 && (ht2_tstride(n) + LAG * GS - LAG) / (LAG * GS) + 2 <= MAXSLOT;
+    return n >= 3 && ht2_need_slots(n) <= MAXSLOT;
 }
 
 // (A, B), B upper triangular -> Hessenberg-triangular, Q <- Q U1, Z <- Z U2 (Q, Z may be NULL).  The reduction
@@ -1126,8 +1129,9 @@ int ht_two_stage_device(hipStream_t s, hipStream_t sq, int n, double *A, int lda
     auto wave_of = [&](int tau_idx) { int jlo = 0, count = 0; wavefront(tau_idx, jlo, count); return Wave2{n, tau_idx, jlo, count, tstride, nslot}; };
     auto open_slots = [&](Wave2 const &w) {            // before the first launch that writes reflectors of w
         int const jhi = w.jlo + w.count - 1;
-        for (; opened <= jhi / GS; opened++)          // a slot is free again once its previous group has been applied
+        for (; opened <= jhi / GS; opened++) {        // a slot is free again once its previous group has been applied
             if (opened >= nslot && sq != s) SN_HIP_CHECK(hipStreamWaitEvent(s, ws.applied[opened % nslot], 0));
+        }
     };
     Wave2 const none{n, 0, 0, 0, tstride, nslot};
     int const nchunk = divceil(n, LEFT_CHUNK) + 1;
